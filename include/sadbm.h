@@ -1,0 +1,116 @@
+/*
+ * sadbm.h -- C ABI of libsadbm: SAD stereo block matching on AMD Instinct MI355X (gfx950).
+ *
+ * Drop-in boundary for the one hot path of the reference project: the free function
+ *     Mat getDisparity(Mat &left, Mat &right)          /root/reference/SAD.cpp:24-61
+ * with its two file-scope parameters  int winSize = 7  (SAD.cpp:9)  and  int DSR = 30  (SAD.cpp:11)
+ * and its helper  int sub_kernel(Mat&, Mat&)           (SAD.cpp:13-22).
+ *
+ * The reference has no FFI of its own; a cv::Mat is (data, rows, cols, channels(), step[0]) and that
+ * is exactly what sadbm_image carries, so a maintainer binds this header from SAD.cpp with a
+ * six-line adapter (see INTEGRATION.md and include/sadbm.hpp).
+ *
+ * Semantics reproduced bit-exactly:
+ *   cost uses channel 0 only (SAD.cpp:19-20); window anchored top-left (SAD.cpp:39,47);
+ *   output rows/cols >= rows-win / cols-win stay 0 (SAD.cpp:31,34,36); disparities with j-k<0 score
+ *   0 (SAD.cpp:40,44-45); first minimum wins (SAD.cpp:54); value = (uchar)(loc*16) (SAD.cpp:57).
+ *
+ * Plain pointers and sizes only; no exceptions cross this boundary; all functions return 0 or a
+ * negative SADBM_E_* code.  There is NO CPU fallback: without a HIP device every compute entry
+ * point fails with SADBM_E_HIP.
+ */
+#ifndef SADBM_H
+#define SADBM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SADBM_VERSION 100
+
+/* flags */
+#define SADBM_RAW_LOC        1u   /* write loc (0..max_disp-1) instead of (loc*16)&255; needs max_disp<=256 */
+#define SADBM_FORCE_GENERIC  2u   /* use the brute-force HIP kernel (any win); for cross-checks */
+
+/* error codes */
+#define SADBM_OK        0
+#define SADBM_E_NULL   -1   /* null pointer argument */
+#define SADBM_E_TYPE   -2   /* channels not in {1,3,4} or left/right channel counts differ
+                               (the reference would throw inside cv::absdiff, SAD.cpp:17) */
+#define SADBM_E_SIZE   -3   /* right smaller than left (the reference would throw in Mat::operator()(Rect),
+                               SAD.cpp:47), negative sizes, or a pitch smaller than a row */
+#define SADBM_E_PARAM  -4   /* win<1, max_disp<1, max_disp>256, win>255 */
+#define SADBM_E_HIP    -5   /* HIP runtime error (sadbm_last_hip_error() has the text) */
+#define SADBM_E_ALLOC  -6   /* device memory allocation failed */
+
+/* Host-memory image view; maps 1:1 onto cv::Mat {data, rows, cols, channels(), step[0]} (CV_8U only).
+ * Replaces the `Mat &left, Mat &right` arguments of getDisparity (SAD.cpp:24). */
+typedef struct {
+    const uint8_t *data;
+    int32_t rows, cols, channels;
+    int64_t step;                 /* bytes between rows */
+} sadbm_image;
+
+/* Caller-allocated CV_8UC1 output; replaces `Mat disparity(row, col, CV_8UC1, Scalar(0))` (SAD.cpp:31). */
+typedef struct {
+    uint8_t *data;
+    int32_t rows, cols;
+    int64_t step;
+} sadbm_plane;
+
+typedef struct sadbm_ctx sadbm_ctx;   /* per (host thread, device) state: scratch planes + a stream */
+
+int         sadbm_version(void);
+const char *sadbm_strerror(int code);
+const char *sadbm_last_hip_error(void);              /* thread-local text of the last SADBM_E_HIP */
+
+/* Context life cycle.  A context owns device scratch (padded single-channel planes) that grows on
+ * demand; use one context per stream.  No reference counterpart (the reference keeps its state in
+ * file-scope globals, SAD.cpp:9-11, and is not re-entrant). */
+int  sadbm_create(int device, sadbm_ctx **out);
+void sadbm_destroy(sadbm_ctx *ctx);
+
+/* getDisparity(left, right) with explicit winSize / DSR (SAD.cpp:24, :9, :11).  Host buffers in, host
+ * buffer out, synchronous.  Every byte of `out` (rows x cols of `left`) is written.  Uses a lazily
+ * created thread-local context on device 0. */
+int sadbm_get_disparity(const sadbm_image *left, const sadbm_image *right, int win, int max_disp,
+                        uint32_t flags, sadbm_plane *out);
+
+/* Same, on an explicit context (any device). */
+int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm_image *right,
+                            int win, int max_disp, uint32_t flags, sadbm_plane *out);
+
+/* Device-resident getDisparity: dL/dR/dOut are device pointers on ctx's device; asynchronous on
+ * `stream` (a hipStream_t passed as void*, NULL = the context's own stream).  channels in {1,3,4}
+ * (channel 0 is used, SAD.cpp:19-20). */
+int sadbm_compute_device(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_t *dR,
+                         int64_t pitchR, int rows, int cols, int channels, int win, int max_disp,
+                         uint32_t flags, uint8_t *dOut, int64_t out_pitch, void *stream);
+
+/* Row band of a larger frame (single-frame multi-GPU split).  The device
+ * buffers hold input rows [row0, row0+rows_in) of a frame that has `frame_rows` rows in total; output
+ * rows [row0, row0+rows_out) are written to dOut (row 0 of dOut = frame row row0).  The loop bound of
+ * SAD.cpp:34 is evaluated on the frame row index, so rows >= frame_rows-win are zero.  Requires
+ * rows_in >= min(rows_out + win - 1, frame_rows - row0). */
+int sadbm_compute_band_device(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_t *dR,
+                              int64_t pitchR, int frame_rows, int row0, int rows_in, int rows_out,
+                              int cols, int channels, int win, int max_disp, uint32_t flags,
+                              uint8_t *dOut, int64_t out_pitch, void *stream);
+
+/* N equally sized pairs (batch data parallelism): pair n lives at
+ * dL + n*pair_stride_in, dR + n*pair_stride_in, dOut + n*pair_stride_out.  One launch sequence for
+ * the whole batch. */
+int sadbm_compute_batch_device(sadbm_ctx *ctx, const uint8_t *dL, const uint8_t *dR, int64_t pitch_in,
+                               int64_t pair_stride_in, int n_pairs, int rows, int cols, int channels,
+                               int win, int max_disp, uint32_t flags, uint8_t *dOut,
+                               int64_t out_pitch, int64_t pair_stride_out, void *stream);
+
+/* Introspection for benchmarks: name and grid of the kernel the last call on this ctx launched. */
+const char *sadbm_last_kernel_name(const sadbm_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SADBM_H */

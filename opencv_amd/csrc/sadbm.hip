@@ -1,0 +1,636 @@
+// sadbm.hip -- SAD stereo block matching for gfx950 (MI355X): HIP kernels + the C ABI of include/sadbm.h.
+//
+// Replaces getDisparity()/sub_kernel() of /root/reference/SAD.cpp:13-61 (see include/sadbm.h for the
+// line-by-line semantics).  Written from scratch for CDNA4; nothing here is derived from the reference's
+// OpenCV-call-per-window structure.
+//
+// Pipeline per call (all on one stream):
+//   1. prep_plane_kernel  x2 : channel 0 of each input -> zero-padded single-channel plane in ctx scratch
+//                              (PADL bytes left, PADR right) so the matcher never needs bounds checks.
+//   2. sad_quad_kernel<WIN>  : the matcher (below).       [sad_generic_kernel for win > MAXWIN]
+//   3. hipMemset2DAsync      : the zero frame (rows >= rows-win), SAD.cpp:31,34.
+//
+// The matcher (DESIGN.md "kernel S"):
+//   * one thread owns 4 adjacent output columns (a "quad", x0 = 4q) and a chunk of KC=16 consecutive
+//     disparities, and marches down a band of rows;
+//   * per row and disparity the four horizontal window sums are built from v_sad_u8 on 4-byte words:
+//     words that lie inside all four windows are summed once, the ragged ends use byte masks;
+//   * the vertical window sum is a running sum in registers:  C += H(row+win-1) - H(row-1);
+//   * costs are accumulated in the high half of a 32-bit register whose low half holds the disparity,
+//     so v_min_u32 on the register IS the first-minimum argmin (cost<<16 | k);
+//   * chunks of one quad live in different threads of the block and are merged through LDS once per row.
+// There is no cross-lane traffic and no LDS in the inner loop; operands come through L1/L2 with
+// unaligned dword loads (the padded planes make x0-k addressable for every k).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <new>
+
+#include "../../include/sadbm.h"
+
+namespace {
+
+constexpr int PADL = 256;     // >= max_disp-1 + slack; keeps x0-k >= -PADL for every disparity
+constexpr int PADR = 64;      // >= 4*NW + 8 for the widest window
+constexpr int KC = 16;        // disparities per thread
+constexpr int MAXWIN = 25;    // widest window with a dedicated instantiation
+constexpr uint32_t KEY_MAX = 0xFFFFFFFFu;
+
+typedef uint32_t __attribute__((aligned(1))) u32u;   // unaligned dword load (global_load_dword handles it)
+
+thread_local char g_hip_err[256] = "";
+
+struct Params {
+    const uint8_t *L, *R;     // padded planes, pointing at column 0 of row 0
+    int64_t plane_stride;     // bytes between planes of consecutive pairs (batch)
+    int pitch;                // plane pitch
+    int W;                    // columns
+    int nvalid;               // output rows [0,nvalid) are computed (they need input rows < nvalid+win-1)
+    int win, D;
+    int NQ, NCp;              // quads per block, chunk slots per block (NQ*NCp = blockDim.x)
+    int TY;                   // output rows per block
+    uint8_t *out;
+    int64_t out_pitch, out_stride;
+    uint32_t flags;
+    int dword_store;          // out base and pitch 4-byte aligned
+};
+
+// ---------------------------------------------------------------------------------------------
+// 1. plane preparation: dst[y][PADL + x] = src[y][x*ch] (channel 0), zero elsewhere.
+//    One thread writes one aligned dword of dst.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) prep_plane_kernel(const uint8_t *__restrict__ src, int64_t step, int64_t src_stride,
+                                                          int ch, int rows, int cols, uint8_t *__restrict__ dst,
+                                                          int pitch, int64_t dst_stride)
+{
+    int wi = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    if (wi * 4 >= pitch || y >= rows) return;
+    const uint8_t *s = src + (int64_t)blockIdx.z * src_stride + (int64_t)y * step;
+    uint32_t v = 0;
+    int xb = wi * 4 - PADL;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        int x = xb + b;
+        if (x >= 0 && x < cols) v |= (uint32_t)s[(int64_t)x * ch] << (8 * b);
+    }
+    *(uint32_t *)(dst + (int64_t)blockIdx.z * dst_stride + (int64_t)y * pitch + wi * 4) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. the matcher
+// ---------------------------------------------------------------------------------------------
+template <int WIN>
+struct Geo {
+    static constexpr int NW = (WIN + 6) / 4;                 // words covering bytes [0, WIN+3) of a quad's span
+    static constexpr bool HI16 = (WIN * WIN * 255 <= 65535); // cost fits the high half of the key
+    // bytes of word j that fall into the window of column x0+a, i.e. positions [a, a+WIN)
+    static constexpr uint32_t mask(int j, int a)
+    {
+        uint32_t m = 0;
+        for (int b = 0; b < 4; ++b) {
+            int pos = 4 * j + b;
+            if (pos >= a && pos < a + WIN) m |= 0xFFu << (8 * b);
+        }
+        return m;
+    }
+    static constexpr bool full(int j, int a) { return mask(j, a) == 0xFFFFFFFFu; }
+    // word j is inside all four windows
+    static constexpr bool shared_all(int j) { return full(j, 0) && full(j, 1) && full(j, 2) && full(j, 3); }
+    // word j is inside the windows of a >= 1..3 but not a = 0 (at most one such j >= 1 exists)
+    static constexpr bool shared_hi(int j) { return j >= 1 && full(j, 3) && !full(j, 0); }
+    static constexpr bool use_hi(int a)
+    {
+        for (int j = 0; j < NW; ++j) if (shared_hi(j) && full(j, a)) return true;
+        return false;
+    }
+};
+
+template <bool HI16>
+__device__ __forceinline__ uint32_t sad_acc(uint32_t a, uint32_t b, uint32_t acc)
+{
+    if constexpr (HI16) return __builtin_amdgcn_sad_hi_u8(a, b, acc);   // acc + (sum|a_i-b_i| << 16)
+    else                return __builtin_amdgcn_sad_u8(a, b, acc);
+}
+
+// Horizontal window sums of one image row for one disparity, folded into the running sums.
+//   ADD:  C[a] += H_a(row)          SUB: C[a] -= H_a(row)
+// Lw: the NW words L[row][x0 .. x0+4NW) ; Rw: the NW words R[row][x0-k .. x0-k+4NW).
+template <int WIN>
+__device__ __forceinline__ void row_bases(const uint32_t (&Lw)[Geo<WIN>::NW], const uint32_t *Rw, uint32_t &b0, uint32_t &b1)
+{
+    using G = Geo<WIN>;
+    b0 = 0;
+#pragma unroll
+    for (int j = 0; j < G::NW; ++j)
+        if (G::shared_all(j)) b0 = sad_acc<G::HI16>(Lw[j], Rw[j], b0);
+    b1 = b0;
+#pragma unroll
+    for (int j = 0; j < G::NW; ++j)
+        if (G::shared_hi(j)) b1 = sad_acc<G::HI16>(Lw[j], Rw[j], b1);
+}
+
+template <int WIN, int A>
+__device__ __forceinline__ uint32_t row_ends(const uint32_t (&Lw)[Geo<WIN>::NW], const uint32_t *Rw, uint32_t acc)
+{
+    using G = Geo<WIN>;
+#pragma unroll
+    for (int j = 0; j < G::NW; ++j) {
+        constexpr int dummy = 0; (void)dummy;
+        const uint32_t m = G::mask(j, A);
+        if (G::shared_all(j)) continue;
+        if (G::shared_hi(j) && G::full(j, A)) continue;
+        if (m == 0) continue;
+        if (m == 0xFFFFFFFFu) acc = sad_acc<G::HI16>(Lw[j], Rw[j], acc);
+        else                  acc = sad_acc<G::HI16>(Lw[j] & m, Rw[j] & m, acc);
+    }
+    return acc;
+}
+
+template <int WIN, int A>
+__device__ __forceinline__ uint32_t base_sel(uint32_t b0, uint32_t b1)
+{
+    // b1 includes the shared_hi word; it applies to alignment A iff that word is full for A
+    return Geo<WIN>::use_hi(A) ? b1 : b0;
+}
+
+template <int WIN>
+__device__ __forceinline__ void load_row_L(const uint8_t *row, int x0, uint32_t (&Lw)[Geo<WIN>::NW])
+{
+#pragma unroll
+    for (int j = 0; j < Geo<WIN>::NW; ++j) Lw[j] = *(const uint32_t *)(row + x0 + 4 * j);
+}
+
+// One marching step for the 16 disparities of this thread.
+//   HAS_OLD = false: C += H(new row)              (warm-up)
+//   HAS_OLD = true : C += H(new row) - H(old row)
+template <int WIN, bool HAS_OLD>
+__device__ __forceinline__ void march_step(const uint8_t *Lnew, const uint8_t *Rnew, const uint8_t *Lold,
+                                           const uint8_t *Rold, int x0, int k0, uint32_t (&C)[KC][4])
+{
+    using G = Geo<WIN>;
+    constexpr int NW = G::NW;
+    uint32_t Ln[NW], Lo[NW];
+    load_row_L<WIN>(Lnew, x0, Ln);
+    if constexpr (HAS_OLD) load_row_L<WIN>(Lold, x0, Lo);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        // disparities k0+c+4t, t=0..3 share byte alignment: word j of disparity t is Wn[j - t + 3]
+        uint32_t Wn[NW + 3], Wo[NW + 3];
+        const uint8_t *pn = Rnew + (x0 - k0 - c - 12);
+#pragma unroll
+        for (int i = 0; i < NW + 3; ++i) Wn[i] = *(const u32u *)(pn + 4 * i);
+        if constexpr (HAS_OLD) {
+            const uint8_t *po = Rold + (x0 - k0 - c - 12);
+#pragma unroll
+            for (int i = 0; i < NW + 3; ++i) Wo[i] = *(const u32u *)(po + 4 * i);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kk = c + 4 * t;
+            const uint32_t *Rn = &Wn[3 - t];
+            uint32_t bn0, bn1, bo0 = 0, bo1 = 0;
+            row_bases<WIN>(Ln, Rn, bn0, bn1);
+            const uint32_t *Ro = &Wo[3 - t];
+            if constexpr (HAS_OLD) row_bases<WIN>(Lo, Ro, bo0, bo1);
+#define SADBM_UPD(A)                                                                        \
+            {                                                                               \
+                uint32_t n = row_ends<WIN, A>(Ln, Rn, C[kk][A]);                            \
+                n += base_sel<WIN, A>(bn0, bn1);                                            \
+                if constexpr (HAS_OLD) n -= row_ends<WIN, A>(Lo, Ro, base_sel<WIN, A>(bo0, bo1)); \
+                C[kk][A] = n;                                                               \
+            }
+            SADBM_UPD(0) SADBM_UPD(1) SADBM_UPD(2) SADBM_UPD(3)
+#undef SADBM_UPD
+        }
+    }
+}
+
+// argmin over this thread's 16 disparities for the four columns of its quad.  `slow` (wave-uniform):
+// some lane sits at the left border (k > x0+a: the reference keeps cost 0 there, handled by the caller
+// through the j+1 candidate) or in the last chunk (k >= D); those slots are excluded.
+template <int WIN>
+__device__ __forceinline__ void chunk_min(const uint32_t (&C)[KC][4], int k0, int kmaxrel0, int dlim, bool slow, uint32_t (&best)[4])
+{
+    using G = Geo<WIN>;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) best[a] = KEY_MAX;
+    if (!slow) {
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                uint32_t key = G::HI16 ? C[kk][a] : ((C[kk][a] << 8) | (uint32_t)(k0 + kk));
+                best[a] = min(best[a], key);
+            }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                uint32_t key = G::HI16 ? C[kk][a] : ((C[kk][a] << 8) | (uint32_t)(k0 + kk));
+                key = (kk <= min(kmaxrel0 + a, dlim)) ? key : KEY_MAX;
+                best[a] = min(best[a], key);
+            }
+    }
+}
+
+template <int WIN>
+__global__ void __launch_bounds__(256) sad_quad_kernel(Params p)
+{
+    using G = Geo<WIN>;
+    __shared__ uint4 merge[2][256];
+
+    const int tid = threadIdx.x;
+    const int q = tid & (p.NQ - 1);
+    const int c = tid / p.NQ;
+    const int x0 = (blockIdx.x * p.NQ + q) * 4;
+    const int k0 = c * KC;
+    const int yb = blockIdx.y * p.TY;
+    const int ny = min(p.TY, p.nvalid - yb);                 // >= 1 by grid construction
+    const uint8_t *L = p.L + (int64_t)blockIdx.z * p.plane_stride;
+    const uint8_t *R = p.R + (int64_t)blockIdx.z * p.plane_stride;
+    uint8_t *out = p.out + (int64_t)blockIdx.z * p.out_stride;
+    const int ocols = p.W - p.win;                            // columns [0,ocols) carry results
+
+    // validity of disparity k0+kk for column x0+a:  k <= min(x0+a, D-1)
+    // kmaxrel0 + a bounds kk for the left border; the D bound is folded in through dlim.
+    const int dlim = p.D - 1 - k0;                            // kk <= dlim
+    const int kmaxrel0 = x0 - k0;                                 // kk <= kmaxrel0 + a
+    // a thread computes iff its quad has an output column and its chunk has a valid disparity
+    const bool active = (x0 < ocols) && (dlim >= 0) && (kmaxrel0 + 3 >= 0);
+    // fold dlim into kmaxrel0 when it is the tighter bound for every a (kk <= min(kmaxrel0+a, dlim))
+    const bool slow_thread = active && (kmaxrel0 < KC - 1 || dlim < KC - 1);
+    const bool slow = __any(slow_thread);
+
+    uint32_t C[KC][4];
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) C[kk][a] = G::HI16 ? (uint32_t)(k0 + kk) : 0u;
+
+    const int nsteps = WIN - 1 + ny;
+    for (int r = 0; r < nsteps; ++r) {
+        const uint8_t *Ln = L + (int64_t)(yb + r) * p.pitch;
+        const uint8_t *Rn = R + (int64_t)(yb + r) * p.pitch;
+        if (active) {
+            if (r < WIN) {
+                march_step<WIN, false>(Ln, Rn, Ln, Rn, x0, k0, C);
+            } else {
+                const uint8_t *Lo = L + (int64_t)(yb + r - WIN) * p.pitch;
+                const uint8_t *Ro = R + (int64_t)(yb + r - WIN) * p.pitch;
+                march_step<WIN, true>(Ln, Rn, Lo, Ro, x0, k0, C);
+            }
+        }
+        if (r < WIN - 1) continue;                            // block-uniform
+
+        // ---- emit output row y ----
+        const int y = yb + r - (WIN - 1);
+        uint32_t best[4] = {KEY_MAX, KEY_MAX, KEY_MAX, KEY_MAX};
+        if (active) chunk_min<WIN>(C, k0, kmaxrel0, dlim, slow, best);
+        if (p.NCp > 1) {
+            const int par = r & 1;
+            if (c > 0) merge[par][tid] = make_uint4(best[0], best[1], best[2], best[3]);
+            __syncthreads();
+            if (c == 0) {
+                for (int cc = 1; cc < p.NCp; ++cc) {
+                    uint4 o = merge[par][cc * p.NQ + q];
+                    best[0] = min(best[0], o.x); best[1] = min(best[1], o.y);
+                    best[2] = min(best[2], o.z); best[3] = min(best[3], o.w);
+                }
+            }
+        }
+        if (c == 0 && x0 < p.W) {
+            uint32_t bytes = 0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int j = x0 + a;
+                uint32_t key = best[a];
+                // SAD.cpp:40,44: slots k>j keep cost 0; the first of them (k=j+1) wins unless a valid
+                // slot has cost 0 (then that smaller k is already the minimum).
+                if (j + 1 < p.D) key = min(key, (uint32_t)(j + 1));
+                uint32_t loc = key & 0xFFu;
+                uint32_t v = (p.flags & SADBM_RAW_LOC) ? loc : ((loc * 16u) & 0xFFu);   // SAD.cpp:57
+                if (j >= ocols) v = 0;
+                bytes |= v << (8 * a);
+            }
+            uint8_t *o = out + (int64_t)y * p.out_pitch + x0;
+            if (p.dword_store && x0 + 3 < p.W) {
+                *(uint32_t *)o = bytes;
+            } else {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    if (x0 + a < p.W) o[a] = (uint8_t)(bytes >> (8 * a));
+            }
+        }
+    }
+}
+
+// Brute-force matcher for any window (win > MAXWIN or SADBM_FORCE_GENERIC): one thread per output
+// pixel, window SAD with v_sad_u8 on bytes from the padded planes.  Correctness path, not tuned.
+__global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= p.W || y >= p.nvalid) return;
+    const uint8_t *L = p.L + (int64_t)blockIdx.z * p.plane_stride;
+    const uint8_t *R = p.R + (int64_t)blockIdx.z * p.plane_stride;
+    uint8_t *out = p.out + (int64_t)blockIdx.z * p.out_stride + (int64_t)y * p.out_pitch;
+    const int ocols = p.W - p.win;
+    if (x >= ocols) { out[x] = 0; return; }
+    const int kmax = min(x, p.D - 1);
+    uint32_t best = KEY_MAX;
+    for (int k = 0; k <= kmax; ++k) {
+        uint32_t cost = 0;
+        for (int dy = 0; dy < p.win; ++dy) {
+            const uint8_t *pl = L + (int64_t)(y + dy) * p.pitch + x;
+            const uint8_t *pr = R + (int64_t)(y + dy) * p.pitch + x - k;
+            for (int dx = 0; dx < p.win; ++dx) cost = __builtin_amdgcn_sad_u8(pl[dx], pr[dx], cost);
+        }
+        best = min(best, (cost << 8) | (uint32_t)k);          // cost < 2^24 for win <= 255
+    }
+    if (x + 1 < p.D) best = min(best, (uint32_t)(x + 1));
+    uint32_t loc = best & 0xFFu;
+    out[x] = (p.flags & SADBM_RAW_LOC) ? (uint8_t)loc : (uint8_t)((loc * 16u) & 0xFFu);
+}
+
+typedef void (*quad_kernel_t)(Params);
+template <int... I> struct Seq {};
+template <int N, int... I> struct MakeSeq : MakeSeq<N - 1, N - 1, I...> {};
+template <int... I> struct MakeSeq<0, I...> { typedef Seq<I...> type; };
+template <int... I>
+static quad_kernel_t pick_quad_kernel(int win, Seq<I...>)
+{
+    static const quad_kernel_t table[] = { sad_quad_kernel<I + 1>... };
+    return table[win - 1];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct sadbm_ctx {
+    int device;
+    hipStream_t stream;          // owned
+    uint8_t *planes;             // scratch: L planes then R planes
+    size_t planes_cap;
+    uint8_t *stage_in;           // host API staging (device copies of the caller's host images)
+    size_t stage_in_cap;
+    uint8_t *stage_out;
+    size_t stage_out_cap;
+    char last_kernel[64];
+};
+
+namespace {
+
+int hip_fail(hipError_t e, const char *what)
+{
+    snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
+    return SADBM_E_HIP;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_, #call); } while (0)
+
+int grow(uint8_t **buf, size_t *cap, size_t need)
+{
+    if (*cap >= need) return SADBM_OK;
+    if (*buf) { hipError_t e = hipFree(*buf); *buf = nullptr; *cap = 0; if (e != hipSuccess) return hip_fail(e, "hipFree"); }
+    size_t want = need + need / 8 + 4096;
+    hipError_t e = hipMalloc((void **)buf, want);
+    if (e != hipSuccess) { *buf = nullptr; hip_fail(e, "hipMalloc"); return SADBM_E_ALLOC; }
+    *cap = want;
+    return SADBM_OK;
+}
+
+int check_params(int rows, int cols, int channels, int win, int max_disp, uint32_t flags)
+{
+    (void)flags;
+    if (rows < 0 || cols < 0) return SADBM_E_SIZE;
+    if (channels != 1 && channels != 3 && channels != 4) return SADBM_E_TYPE;
+    if (win < 1 || win > 255 || max_disp < 1 || max_disp > 256) return SADBM_E_PARAM;
+    return SADBM_OK;
+}
+
+int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// The whole device pipeline for n_pairs frames (or one band).  Input rows available: rows_in; output
+// rows written: rows_out; output rows [0,nvalid) are computed, the rest zero-filled.
+int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_t *dR, int64_t pitchR,
+                 int64_t pair_stride_in, int n_pairs, int rows_in, int rows_out, int nvalid, int cols, int channels,
+                 int win, int D, uint32_t flags, uint8_t *dOut, int64_t out_pitch, int64_t pair_stride_out,
+                 hipStream_t st)
+{
+    if (n_pairs <= 0 || rows_out <= 0 || cols <= 0) return SADBM_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (nvalid < 0) nvalid = 0;
+    if (cols - win <= 0) nvalid = 0;
+    // zero frame: rows [nvalid, rows_out) entirely (SAD.cpp:31,34); columns >= cols-win are written
+    // as zeros by the matcher itself.
+    if (nvalid < rows_out) {
+        for (int n = 0; n < n_pairs; ++n)
+            HIPCHK(hipMemset2DAsync(dOut + (int64_t)n * pair_stride_out + (int64_t)nvalid * out_pitch, (size_t)out_pitch, 0,
+                                    (size_t)cols, (size_t)(rows_out - nvalid), st));
+    }
+    if (nvalid == 0) { snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "none"); return SADBM_OK; }
+
+    const int need_rows = nvalid + win - 1;                   // <= rows_in (checked by callers)
+    const int pitch = (PADL + cols + PADR + 127) & ~127;
+    const size_t plane_bytes = (size_t)pitch * (size_t)need_rows;
+    int rc = grow(&ctx->planes, &ctx->planes_cap, 2 * plane_bytes * (size_t)n_pairs);
+    if (rc) return rc;
+    uint8_t *pL = ctx->planes, *pR = ctx->planes + plane_bytes * (size_t)n_pairs;
+
+    dim3 pg((pitch / 4 + 255) / 256, need_rows, n_pairs);
+    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dL, pitchL, pair_stride_in, channels, need_rows, cols, pL, pitch, (int64_t)plane_bytes);
+    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dR, pitchR, pair_stride_in, channels, need_rows, cols, pR, pitch, (int64_t)plane_bytes);
+    HIPCHK(hipGetLastError());
+
+    Params p;
+    p.L = pL + PADL; p.R = pR + PADL; p.plane_stride = (int64_t)plane_bytes; p.pitch = pitch;
+    p.W = cols; p.nvalid = nvalid; p.win = win; p.D = D;
+    p.out = dOut; p.out_pitch = out_pitch; p.out_stride = pair_stride_out; p.flags = flags;
+    p.dword_store = ((((uintptr_t)dOut) | (uintptr_t)out_pitch | (uintptr_t)pair_stride_out) & 3) == 0;
+    p.NQ = 0; p.NCp = 0; p.TY = 0;
+
+    if (win > MAXWIN || (flags & SADBM_FORCE_GENERIC)) {
+        dim3 g((cols + 255) / 256, nvalid, n_pairs);
+        hipLaunchKernelGGL(sad_generic_kernel, g, dim3(256), 0, st, p);
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_generic_kernel");
+    } else {
+        const int NC = (D + KC - 1) / KC;                     // <= 16
+        p.NCp = pow2ceil(NC);
+        const int quads = (cols + 3) / 4;
+        p.NQ = 256 / p.NCp;
+        if (p.NQ > 16 && p.NQ > pow2ceil(quads)) p.NQ = pow2ceil(quads) < 16 ? 16 : pow2ceil(quads);
+        const int bx = (quads + p.NQ - 1) / p.NQ;
+        // rows per block: long bands amortise the win-1 warm-up rows; shorten them until the grid
+        // has a few blocks per CU.
+        int TY = 64;
+        while (TY > 16 && (long)bx * ((nvalid + TY - 1) / TY) * n_pairs < 1024) TY >>= 1;
+        p.TY = TY;
+        dim3 g(bx, (nvalid + TY - 1) / TY, n_pairs);
+        quad_kernel_t k = pick_quad_kernel(win, MakeSeq<MAXWIN>::type());
+        hipLaunchKernelGGL(k, g, dim3(p.NQ * p.NCp), 0, st, p);
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_quad_kernel<%d>", win);
+    }
+    HIPCHK(hipGetLastError());
+    return SADBM_OK;
+}
+
+thread_local sadbm_ctx *g_tls_ctx = nullptr;
+
+}  // namespace
+
+extern "C" {
+
+int sadbm_version(void) { return SADBM_VERSION; }
+
+const char *sadbm_strerror(int code)
+{
+    switch (code) {
+    case SADBM_OK: return "ok";
+    case SADBM_E_NULL: return "null pointer argument";
+    case SADBM_E_TYPE: return "unsupported channel count or left/right channel mismatch";
+    case SADBM_E_SIZE: return "bad image size or pitch (right must be at least as large as left)";
+    case SADBM_E_PARAM: return "bad parameter (need 1<=win<=255, 1<=max_disp<=256)";
+    case SADBM_E_HIP: return "HIP runtime error";
+    case SADBM_E_ALLOC: return "device memory allocation failed";
+    default: return "unknown error";
+    }
+}
+
+const char *sadbm_last_hip_error(void) { return g_hip_err; }
+
+int sadbm_create(int device, sadbm_ctx **out)
+{
+    if (!out) return SADBM_E_NULL;
+    *out = nullptr;
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) { snprintf(g_hip_err, sizeof(g_hip_err), "device %d of %d", device, n); return SADBM_E_HIP; }
+    HIPCHK(hipSetDevice(device));
+    sadbm_ctx *c = new (std::nothrow) sadbm_ctx();
+    if (!c) return SADBM_E_ALLOC;
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+    snprintf(c->last_kernel, sizeof(c->last_kernel), "none");
+    *out = c;
+    return SADBM_OK;
+}
+
+void sadbm_destroy(sadbm_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->planes) (void)hipFree(c->planes);
+    if (c->stage_in) (void)hipFree(c->stage_in);
+    if (c->stage_out) (void)hipFree(c->stage_out);
+    if (g_tls_ctx == c) g_tls_ctx = nullptr;
+    delete c;
+}
+
+const char *sadbm_last_kernel_name(const sadbm_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
+
+int sadbm_compute_band_device(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_t *dR, int64_t pitchR,
+                              int frame_rows, int row0, int rows_in, int rows_out, int cols, int channels, int win,
+                              int max_disp, uint32_t flags, uint8_t *dOut, int64_t out_pitch, void *stream)
+{
+    if (!ctx) return SADBM_E_NULL;
+    int rc = check_params(frame_rows, cols, channels, win, max_disp, flags);
+    if (rc) return rc;
+    if (row0 < 0 || rows_in < 0 || rows_out < 0 || row0 + rows_out > frame_rows || row0 + rows_in > frame_rows) return SADBM_E_SIZE;
+    if (rows_out == 0 || cols == 0) return SADBM_OK;
+    if (!dL || !dR || !dOut) return SADBM_E_NULL;
+    if (pitchL < (int64_t)cols * channels || pitchR < (int64_t)cols * channels || out_pitch < cols) return SADBM_E_SIZE;
+    int nvalid = frame_rows - win - row0;                     // SAD.cpp:34 on the frame row index
+    if (nvalid > rows_out) nvalid = rows_out;
+    if (nvalid < 0) nvalid = 0;
+    if (cols - win <= 0) nvalid = 0;
+    if (nvalid > 0 && rows_in < nvalid + win - 1) return SADBM_E_SIZE;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    return run_pipeline(ctx, dL, pitchL, dR, pitchR, 0, 1, rows_in, rows_out, nvalid, cols, channels, win, max_disp, flags,
+                        dOut, out_pitch, 0, st);
+}
+
+int sadbm_compute_device(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_t *dR, int64_t pitchR, int rows,
+                         int cols, int channels, int win, int max_disp, uint32_t flags, uint8_t *dOut,
+                         int64_t out_pitch, void *stream)
+{
+    return sadbm_compute_band_device(ctx, dL, pitchL, dR, pitchR, rows, 0, rows, rows, cols, channels, win, max_disp,
+                                     flags, dOut, out_pitch, stream);
+}
+
+int sadbm_compute_batch_device(sadbm_ctx *ctx, const uint8_t *dL, const uint8_t *dR, int64_t pitch_in,
+                               int64_t pair_stride_in, int n_pairs, int rows, int cols, int channels, int win,
+                               int max_disp, uint32_t flags, uint8_t *dOut, int64_t out_pitch,
+                               int64_t pair_stride_out, void *stream)
+{
+    if (!ctx) return SADBM_E_NULL;
+    int rc = check_params(rows, cols, channels, win, max_disp, flags);
+    if (rc) return rc;
+    if (n_pairs < 0) return SADBM_E_SIZE;
+    if (n_pairs == 0 || rows == 0 || cols == 0) return SADBM_OK;
+    if (!dL || !dR || !dOut) return SADBM_E_NULL;
+    if (pitch_in < (int64_t)cols * channels || out_pitch < cols) return SADBM_E_SIZE;
+    if (n_pairs > 1 && (pair_stride_in < pitch_in * (int64_t)rows || pair_stride_out < out_pitch * (int64_t)rows)) return SADBM_E_SIZE;
+    int nvalid = rows - win;
+    if (nvalid < 0 || cols - win <= 0) nvalid = 0;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    // grid.z carries the pair index (<= 65535 per launch)
+    for (int n0 = 0; n0 < n_pairs; n0 += 32768) {
+        int nn = n_pairs - n0 < 32768 ? n_pairs - n0 : 32768;
+        rc = run_pipeline(ctx, dL + (int64_t)n0 * pair_stride_in, pitch_in, dR + (int64_t)n0 * pair_stride_in, pitch_in,
+                          pair_stride_in, nn, rows, rows, nvalid, cols, channels, win, max_disp, flags,
+                          dOut + (int64_t)n0 * pair_stride_out, out_pitch, pair_stride_out, st);
+        if (rc) return rc;
+    }
+    return SADBM_OK;
+}
+
+int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm_image *right, int win, int max_disp,
+                            uint32_t flags, sadbm_plane *out)
+{
+    if (!ctx || !left || !right || !out) return SADBM_E_NULL;
+    int rc = check_params(left->rows, left->cols, left->channels, win, max_disp, flags);
+    if (rc) return rc;
+    if (right->channels != left->channels) return SADBM_E_TYPE;             // cv::absdiff would throw (SAD.cpp:17)
+    if (right->rows < left->rows || right->cols < left->cols) return SADBM_E_SIZE;   // Mat ROI would throw (SAD.cpp:47)
+    if (out->rows != left->rows || out->cols != left->cols) return SADBM_E_SIZE;
+    const int rows = left->rows, cols = left->cols, ch = left->channels;
+    if (rows == 0 || cols == 0) return SADBM_OK;                             // empty Mat: loops skipped (SAD.cpp:26-36)
+    if (!left->data || !right->data || !out->data) return SADBM_E_NULL;
+    const size_t rowb = (size_t)cols * ch;
+    if (left->step < (int64_t)rowb || right->step < (int64_t)rowb || out->step < cols) return SADBM_E_SIZE;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t pin = (rowb + 255) & ~(size_t)255, pout = ((size_t)cols + 255) & ~(size_t)255;
+    rc = grow(&ctx->stage_in, &ctx->stage_in_cap, 2 * pin * rows);
+    if (rc) return rc;
+    rc = grow(&ctx->stage_out, &ctx->stage_out_cap, pout * rows);
+    if (rc) return rc;
+    uint8_t *dL = ctx->stage_in, *dR = ctx->stage_in + pin * rows;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipMemcpy2DAsync(dL, pin, left->data, (size_t)left->step, rowb, rows, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpy2DAsync(dR, pin, right->data, (size_t)right->step, rowb, rows, hipMemcpyHostToDevice, st));
+    rc = sadbm_compute_device(ctx, dL, (int64_t)pin, dR, (int64_t)pin, rows, cols, ch, win, max_disp, flags, ctx->stage_out,
+                              (int64_t)pout, st);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy2DAsync(out->data, (size_t)out->step, ctx->stage_out, pout, (size_t)cols, rows, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return SADBM_OK;
+}
+
+int sadbm_get_disparity(const sadbm_image *left, const sadbm_image *right, int win, int max_disp, uint32_t flags,
+                        sadbm_plane *out)
+{
+    if (!g_tls_ctx) {
+        int rc = sadbm_create(0, &g_tls_ctx);
+        if (rc) return rc;
+    }
+    return sadbm_get_disparity_ctx(g_tls_ctx, left, right, win, max_disp, flags, out);
+}
+
+}  // extern "C"

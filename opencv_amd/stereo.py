@@ -1,0 +1,277 @@
+"""Python host layer over libsadbm.so (ctypes).  Mirrors /root/reference/SAD.cpp's call surface:
+
+    Mat getDisparity(Mat &left, Mat &right)        SAD.cpp:24   with globals winSize=7 (:9), DSR=30 (:11)
+
+`getDisparity(left, right, winSize=7, DSR=30)` takes HxW or HxWxC uint8 arrays (numpy, host) or
+torch CUDA tensors (device-resident path) and returns the HxW uint8 disparity image.  torch is used
+only for device memory and streams; all arithmetic happens in the HIP kernels.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+RAW_LOC = 1
+FORCE_GENERIC = 2
+DEFAULT_WIN_SIZE = 7     # SAD.cpp:9
+DEFAULT_DSR = 30         # SAD.cpp:11
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_SO = os.path.join(_CSRC, "libsadbm.so")
+_lib = None
+
+
+class SadbmError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("sadbm error %d: %s" % (code, text))
+        self.code = code
+
+
+class _Image(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("channels", ctypes.c_int32), ("step", ctypes.c_int64)]
+
+
+class _Plane(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("step", ctypes.c_int64)]
+
+
+def library_path():
+    return _SO
+
+
+def build_library(force=False):
+    """Compile csrc/sadbm.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src = os.path.join(_CSRC, "sadbm.hip")
+    hdr = os.path.join(_HERE, "..", "include", "sadbm.h")
+    stale = (not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src)
+             or os.path.getmtime(_SO) < os.path.getmtime(hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _CSRC, "-B", "libsadbm.so"])
+    return _SO
+
+
+def load_library():
+    """dlopen libsadbm.so; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise SadbmError(-100, "libsadbm.so not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                               "there is no CPU fallback")
+    L = ctypes.CDLL(_SO)
+    vp, i32, i64, u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint32
+    L.sadbm_version.restype = i32
+    L.sadbm_strerror.restype = ctypes.c_char_p
+    L.sadbm_strerror.argtypes = [i32]
+    L.sadbm_last_hip_error.restype = ctypes.c_char_p
+    L.sadbm_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.sadbm_destroy.argtypes = [vp]
+    L.sadbm_destroy.restype = None
+    L.sadbm_get_disparity.argtypes = [ctypes.POINTER(_Image), ctypes.POINTER(_Image), i32, i32, u32, ctypes.POINTER(_Plane)]
+    L.sadbm_get_disparity_ctx.argtypes = [vp] + L.sadbm_get_disparity.argtypes
+    L.sadbm_compute_device.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, u32, vp, i64, vp]
+    L.sadbm_compute_band_device.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, u32, vp, i64, vp]
+    L.sadbm_compute_batch_device.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, u32, vp, i64, i64, vp]
+    L.sadbm_last_kernel_name.argtypes = [vp]
+    L.sadbm_last_kernel_name.restype = ctypes.c_char_p
+    for name in ("sadbm_create", "sadbm_get_disparity", "sadbm_get_disparity_ctx", "sadbm_compute_device",
+                 "sadbm_compute_band_device", "sadbm_compute_batch_device"):
+        getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        L = load_library()
+        text = L.sadbm_strerror(rc).decode()
+        if rc == -5:
+            text += " (" + L.sadbm_last_hip_error().decode() + ")"
+        raise SadbmError(rc, text)
+
+
+class Context:
+    """One sadbm_ctx: device scratch + a stream.  One per (thread, device, stream)."""
+
+    def __init__(self, device=0):
+        L = load_library()
+        h = ctypes.c_void_p()
+        _check(L.sadbm_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().sadbm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def last_kernel(self):
+        return load_library().sadbm_last_kernel_name(self._h).decode()
+
+
+_default_ctx = {}
+
+
+def _ctx_for(device):
+    c = _default_ctx.get(device)
+    if c is None:
+        c = _default_ctx[device] = Context(device)
+    return c
+
+
+def _host_views(left, right):
+    left = np.asarray(left)
+    right = np.asarray(right)
+    if left.dtype != np.uint8 or right.dtype != np.uint8:
+        raise SadbmError(-2, "images must be uint8 (CV_8U)")
+    if left.ndim == 2:
+        left = left[:, :, None]
+    if right.ndim == 2:
+        right = right[:, :, None]
+    if left.ndim != 3 or right.ndim != 3:
+        raise SadbmError(-3, "images must be HxW or HxWxC")
+    out = []
+    for a in (left, right):
+        # ROI views with a row stride are passed through (cv::Mat step); pixels must be contiguous
+        ch = a.shape[2]
+        ok = (ch == 1 or a.strides[2] == 1) and (a.shape[1] <= 1 or a.strides[1] == ch) and \
+             (a.shape[0] <= 1 or a.strides[0] >= a.shape[1] * ch)
+        out.append(a if ok else np.ascontiguousarray(a))
+    return out
+
+
+def get_disparity_host(left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags=0, ctx=None):
+    """Host arrays in, host array out (sadbm_get_disparity / _ctx)."""
+    L = load_library()
+    left, right = _host_views(left, right)
+    rows, cols, ch = left.shape
+    out = np.empty((rows, cols), dtype=np.uint8)
+    li = _Image(left.ctypes.data, rows, cols, ch, left.strides[0] if rows > 1 else max(cols * ch, 1))
+    ri = _Image(right.ctypes.data, right.shape[0], right.shape[1], right.shape[2],
+                right.strides[0] if right.shape[0] > 1 else max(right.shape[1] * right.shape[2], 1))
+    op = _Plane(out.ctypes.data, rows, cols, max(cols, 1))
+    if ctx is None:
+        _check(L.sadbm_get_disparity(ctypes.byref(li), ctypes.byref(ri), int(winSize), int(DSR), int(flags), ctypes.byref(op)))
+    else:
+        _check(L.sadbm_get_disparity_ctx(ctx.handle, ctypes.byref(li), ctypes.byref(ri), int(winSize), int(DSR), int(flags), ctypes.byref(op)))
+    return out
+
+
+def _tensor_view(t):
+    """(ptr, pitch, rows, cols, channels) of a uint8 CUDA tensor HxW or HxWxC with contiguous pixels."""
+    import torch
+    if t.dtype != torch.uint8 or not t.is_cuda:
+        raise SadbmError(-2, "device path needs uint8 CUDA tensors")
+    if t.dim() == 2:
+        t = t.unsqueeze(-1)
+    if t.dim() != 3:
+        raise SadbmError(-3, "images must be HxW or HxWxC")
+    rows, cols, ch = t.shape
+    if cols > 0 and rows > 0 and (t.stride(2) != 1 or (cols > 1 and t.stride(1) != ch)):
+        t = t.contiguous()
+    pitch = t.stride(0) if rows > 1 else max(cols * ch, 1)
+    return t, t.data_ptr(), pitch, rows, cols, ch
+
+
+def _stream_ptr(device):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def compute_device(left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags=0, out=None, ctx=None):
+    """Device-resident getDisparity on torch CUDA tensors (sadbm_compute_device), async on the
+    current torch stream."""
+    import torch
+    L = load_library()
+    lt, lp, lpitch, rows, cols, ch = _tensor_view(left)
+    rt, rp, rpitch, rrows, rcols, rch = _tensor_view(right)
+    if rch != ch:
+        raise SadbmError(-2, L.sadbm_strerror(-2).decode())
+    if rrows < rows or rcols < cols:
+        raise SadbmError(-3, L.sadbm_strerror(-3).decode())
+    dev = left.device.index or 0
+    ctx = ctx or _ctx_for(dev)
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.uint8, device=left.device)
+    opitch = out.stride(0) if rows > 1 else max(cols, 1)
+    with torch.cuda.device(dev):
+        _check(L.sadbm_compute_device(ctx.handle, lp, lpitch, rp, rpitch, rows, cols, ch, int(winSize), int(DSR), int(flags),
+                                      out.data_ptr(), opitch, _stream_ptr(dev)))
+    return out
+
+
+def compute_band_device(left_band, right_band, frame_rows, row0, rows_out, winSize, DSR, flags=0, out=None, ctx=None):
+    """Row band [row0, row0+rows_out) of a frame of `frame_rows` rows; left_band/right_band hold input
+    rows [row0, row0+left_band.shape[0]) (sadbm_compute_band_device)."""
+    import torch
+    L = load_library()
+    lt, lp, lpitch, rows_in, cols, ch = _tensor_view(left_band)
+    rt, rp, rpitch, rrows, rcols, rch = _tensor_view(right_band)
+    if rch != ch:
+        raise SadbmError(-2, L.sadbm_strerror(-2).decode())
+    if rrows < rows_in or rcols < cols:
+        raise SadbmError(-3, L.sadbm_strerror(-3).decode())
+    dev = left_band.device.index or 0
+    ctx = ctx or _ctx_for(dev)
+    if out is None:
+        out = torch.empty((rows_out, cols), dtype=torch.uint8, device=left_band.device)
+    opitch = out.stride(0) if rows_out > 1 else max(cols, 1)
+    with torch.cuda.device(dev):
+        _check(L.sadbm_compute_band_device(ctx.handle, lp, lpitch, rp, rpitch, int(frame_rows), int(row0), rows_in,
+                                           int(rows_out), cols, ch, int(winSize), int(DSR), int(flags),
+                                           out.data_ptr(), opitch, _stream_ptr(dev)))
+    return out
+
+
+def compute_batch_device(left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags=0, out=None, ctx=None):
+    """N pairs at once: left/right are NxHxW (or NxHxWxC) contiguous uint8 CUDA tensors."""
+    import torch
+    L = load_library()
+    if left.dim() == 3:
+        left = left.unsqueeze(-1)
+        right = right.unsqueeze(-1)
+    left = left.contiguous()
+    right = right.contiguous()
+    if left.shape != right.shape:
+        raise SadbmError(-3, "batched left/right must have equal shapes")
+    n, rows, cols, ch = left.shape
+    dev = left.device.index or 0
+    ctx = ctx or _ctx_for(dev)
+    if out is None:
+        out = torch.empty((n, rows, cols), dtype=torch.uint8, device=left.device)
+    with torch.cuda.device(dev):
+        _check(L.sadbm_compute_batch_device(ctx.handle, left.data_ptr(), right.data_ptr(), cols * ch, rows * cols * ch, n,
+                                            rows, cols, ch, int(winSize), int(DSR), int(flags), out.data_ptr(),
+                                            cols, rows * cols, _stream_ptr(dev)))
+    return out
+
+
+def getDisparity(left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags=0):
+    """Drop-in for SAD.cpp:24 `Mat getDisparity(Mat &left, Mat &right)`.
+
+    numpy arrays -> host path (H2D, kernels, D2H, synchronous); torch CUDA tensors -> device path
+    (asynchronous on the current stream).  Returns an HxW uint8 image of (loc*16)&255 (SAD.cpp:57).
+    """
+    try:
+        import torch
+        if isinstance(left, torch.Tensor):
+            if left.is_cuda:
+                return compute_device(left, right, winSize, DSR, flags)
+            return torch.from_numpy(get_disparity_host(left.numpy(), right.numpy(), winSize, DSR, flags))
+    except ImportError:
+        pass
+    return get_disparity_host(left, right, winSize, DSR, flags)

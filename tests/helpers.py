@@ -1,0 +1,50 @@
+"""Shared test helpers (fixtures are data; the oracle is the checker)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def read_pnm(path):
+    with open(path, "rb") as f:
+        data = f.read()
+    parts = data.split(b"\n", 3)
+    magic, dims, maxv, body = parts
+    w, h = (int(v) for v in dims.split())
+    assert maxv == b"255"
+    if magic == b"P5":
+        return np.frombuffer(body, dtype=np.uint8).reshape(h, w).copy()
+    assert magic == b"P6"
+    return np.frombuffer(body, dtype=np.uint8).reshape(h, w, 3).copy()
+
+
+def golden_meta():
+    with open(os.path.join(GOLDEN, "golden.json")) as f:
+        return json.load(f)
+
+
+def tsukuba_bgr():
+    """left/right as cv::imread(path) would return them: 8-bit 3-channel BGR (SAD.cpp:65-66)."""
+    l = read_pnm(os.path.join(GOLDEN, "tsukuba_left.ppm"))[:, :, ::-1]
+    r = read_pnm(os.path.join(GOLDEN, "tsukuba_right.ppm"))[:, :, ::-1]
+    return np.ascontiguousarray(l), np.ascontiguousarray(r)
+
+
+def noise_pair(seed, H, W, shift=None, binary=False, ch=1):
+    rng = np.random.default_rng(seed)
+    shape = (H, W) if ch == 1 else (H, W, ch)
+    L = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    R = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    if shift is not None:
+        R[:, : W - shift] = L[:, shift:]
+    if binary:
+        L = np.where(L & 0x80, 255, 0).astype(np.uint8)
+        R = np.where(R & 0x80, 255, 0).astype(np.uint8)
+    return L, R

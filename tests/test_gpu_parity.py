@@ -1,0 +1,156 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Every call goes through the C ABI of
+include/sadbm.h (ctypes -> libsadbm.so -> HIP kernels) and is compared bit-for-bit with the CPU
+oracle and the committed golden fixtures.  Bar: bit-exact (integer/byte path)."""
+import numpy as np
+import pytest
+
+import opencv_amd as oa
+import oracle
+from helpers import GOLDEN, noise_pair, read_pnm, sha, tsukuba_bgr
+
+pytestmark = pytest.mark.gpu
+
+
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def dev(a):
+    return torch_cuda().from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_library_is_the_hip_build():
+    assert oa.load_library().sadbm_version() == 100
+
+
+def test_config1_tsukuba_golden_host_api():
+    """BASELINE config 1 through sadbm_get_disparity (host buffers, BGR, channel 0 on device)."""
+    L, R = tsukuba_bgr()
+    out = oa.getDisparity(L, R)                                   # defaults winSize=7, DSR=30 (SAD.cpp:9,11)
+    assert np.array_equal(out, read_pnm(GOLDEN + "/tsukuba_disp_w7_d30.pgm"))
+    assert sha(out) == "7da39f56141fbb2fc045c375b5be9fe84e8620beabec3009c99a5194075ea166"
+    raw = oa.get_disparity_host(L, R, 7, 30, oa.RAW_LOC)
+    assert np.array_equal(raw, read_pnm(GOLDEN + "/tsukuba_loc_w7_d30.pgm"))
+    gen = oa.get_disparity_host(L, R, 7, 30, oa.FORCE_GENERIC)
+    assert np.array_equal(gen, out)
+
+
+@pytest.mark.parametrize("tag,binary", [("u8", 0), ("bin", 1)])
+def test_rds_golden_device_api(tag, binary):
+    L, R = oracle.rds(1, 320, 240, 4, 20, binary)
+    out = oa.compute_device(dev(L), dev(R), 9, 64).cpu().numpy()
+    assert np.array_equal(out, read_pnm(GOLDEN + "/rds_seed1_320x240_w9_d64_%s_disp.pgm" % tag))
+
+
+@pytest.mark.parametrize("win", [1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 21, 25, 27])
+@pytest.mark.parametrize("D", [1, 16, 30, 64, 128, 256])
+def test_sweep_matches_oracle(win, D):
+    H, W = 61, 203                       # odd sizes, not multiples of any tile
+    for binary in (False, True):
+        L, R = noise_pair(win * 977 + D, H, W, shift=5, binary=binary)
+        exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
+        got = oa.get_disparity_host(L, R, win, D, oa.RAW_LOC)
+        assert np.array_equal(got, exp), (win, D, binary, np.argwhere(got != exp)[:5])
+
+
+@pytest.mark.parametrize("shape", [(9, 300), (300, 9), (40, 17), (8, 8), (7, 50), (50, 7), (1, 1), (33, 129)])
+def test_small_and_degenerate_shapes(shape):
+    H, W = shape
+    L, R = noise_pair(H * 31 + W, H, W)
+    for win, D in ((7, 30), (3, 64), (9, 256)):
+        exp = oracle.literal(L, R, win, D)
+        got = oa.get_disparity_host(L, R, win, D)
+        assert np.array_equal(got, exp), (shape, win, D)
+
+
+def test_w_less_than_d_and_constant_and_identical():
+    L, R = noise_pair(4, 30, 40)
+    assert np.array_equal(oa.get_disparity_host(L, R, 5, 128), oracle.literal(L, R, 5, 128))
+    c1 = np.full((30, 90), 10, np.uint8)
+    c2 = np.full((30, 90), 200, np.uint8)
+    assert np.array_equal(oa.get_disparity_host(c1, c2, 5, 16, oa.RAW_LOC), oracle.literal(c1, c2, 5, 16, oracle.RAW_LOC))
+    assert not oa.get_disparity_host(L, L, 7, 30, oa.RAW_LOC).any()           # K1
+
+
+@pytest.mark.parametrize("ch", [3, 4])
+def test_multichannel_uses_plane0(ch):
+    L, R = noise_pair(17 + ch, 50, 77, ch=ch)
+    exp = oracle.literal(np.ascontiguousarray(L[:, :, 0]), np.ascontiguousarray(R[:, :, 0]), 7, 30)
+    assert np.array_equal(oa.get_disparity_host(L, R, 7, 30), exp)
+    assert np.array_equal(oa.compute_device(dev(L), dev(R), 7, 30).cpu().numpy(), exp)
+
+
+def test_roi_views_with_step_and_larger_right():
+    bl, br = noise_pair(23, 80, 160)
+    L = bl[10:70, 16:140]
+    R = br[10:70, 16:140]
+    exp = oracle.literal(np.ascontiguousarray(L), np.ascontiguousarray(R), 7, 30)
+    assert np.array_equal(oa.get_disparity_host(L, R, 7, 30), exp)
+    # a larger right image is legal; its extra area is ignored (SAD.cpp:26-27 reads only left's size)
+    Rbig = br[10:75, 16:150]
+    assert np.array_equal(oa.get_disparity_host(L, Rbig, 7, 30), exp)
+    # device tensors with a row pitch and an unaligned output view
+    torch = torch_cuda()
+    dl = dev(bl)[10:70, 16:140]
+    dr = dev(br)[10:70, 16:140]
+    obuf = torch.zeros((60, 131), dtype=torch.uint8, device="cuda")
+    out = obuf[:, 3:127]
+    oa.compute_device(dl, dr, 7, 30, out=out)
+    assert np.array_equal(out.cpu().numpy(), exp)
+    assert not obuf[:, :3].any() and not obuf[:, 127:].any()
+
+
+def test_errors_match_reference_failure_modes():
+    L, R = noise_pair(2, 20, 20)
+    with pytest.raises(oa.SadbmError) as e:
+        oa.get_disparity_host(L, R[:19], 7, 30)
+    assert e.value.code == -3
+    with pytest.raises(oa.SadbmError) as e:
+        oa.get_disparity_host(np.stack([L] * 3, -1), R, 7, 30)
+    assert e.value.code == -2
+    with pytest.raises(oa.SadbmError) as e:
+        oa.get_disparity_host(L, R, 0, 30)
+    assert e.value.code == -4
+
+
+def test_batch_matches_per_pair():
+    torch = torch_cuda()
+    n, H, W = 5, 47, 131
+    Ls, Rs = zip(*[oracle.rds(1000 + i, W, H, 5 + i, 20 + i, 0) for i in range(n)])
+    out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), 7, 64).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], 7, 64)), i
+
+
+@pytest.mark.parametrize("nb", [1, 2, 3, 8])
+def test_row_bands_concatenate_to_full_frame(nb):
+    H, W, win, D = 83, 140, 9, 40
+    L, R = noise_pair(77, H, W, shift=4)
+    exp = oracle.box(L, R, win, D)
+    per, ranges = oa.band_ranges(H, nb)
+    parts = []
+    for (r0, r1) in ranges:
+        if r1 == r0:
+            continue
+        i0, i1 = oa.band_input_rows(r0, r1, H, win)
+        parts.append(oa.compute_band_device(dev(L[i0:i1]), dev(R[i0:i1]), H, r0, r1 - r0, win, D).cpu().numpy())
+    assert np.array_equal(np.concatenate(parts, 0), exp)
+
+
+def test_repeatability_is_bit_exact():
+    L, R = oracle.rds(9, 640, 360, 8, 40, 0)
+    a = oa.compute_device(dev(L), dev(R), 9, 64).cpu().numpy()
+    for _ in range(3):
+        assert np.array_equal(a, oa.compute_device(dev(L), dev(R), 9, 64).cpu().numpy())
+
+
+def test_full_size_1080p_config2_against_box_oracle():
+    """BASELINE config 2 at full size: rds(2,1920,1080,8,40), 9x9, D=64 vs the sliding-sum oracle."""
+    L, R = oracle.rds(2, 1920, 1080, 8, 40, 0)
+    got = oa.compute_device(dev(L), dev(R), 9, 64, oa.RAW_LOC).cpu().numpy()
+    exp = oracle.box(L, R, 9, 64, oracle.RAW_LOC)
+    assert np.array_equal(got, exp)
+    # size-independent property: interior of background/foreground recovers the planted disparities
+    assert (got[100, 100:300] == 8).all() and (got[500, 700:1100] == 40).all()

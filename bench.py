@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the SAD stereo matcher on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one rank
+per GPU).  A step = one pass of the hot path (sadbm_compute_batch_device: plane prep + matcher +
+zero frame) over one batch of synthetic stereo pairs that are already resident in HBM.  Default
+workload = BASELINE.json configs[2], the config the metric is quoted on: rds(3,3840,2160,16,96),
+15x15 window, D=128.  Multi-GPU = batch data parallelism: every rank processes its own batch, no
+data-path collective (weak scaling); value = evals of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (W, H, win, D, rds seed, d_bg, d_fg, pairs per step)
+    "cfg2_1080p_w9_d64": (1920, 1080, 9, 64, 2, 8, 40, 4),
+    "cfg2b_1080p_w9_d128": (1920, 1080, 9, 128, 2, 8, 40, 4),
+    "cfg3_4k_w15_d128": (3840, 2160, 15, 128, 3, 16, 96, 2),
+    "cfg4_8k_w21_d256": (7680, 4320, 21, 256, 4, 32, 200, 1),
+    "cfg5_kitti_w7_d128": (1242, 375, 7, 128, 1000, 5, 60, 64),
+}
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_NOMINAL_TOPS = 39.3         # 256 CU x 64 lanes x 2.4 GHz lane-ops/s (4-cycle wave64 issue)
+
+
+def cpu_baseline(L, R, win, D, threads):
+    """Oracle (port of the reference loop, OpenMP over rows) on a bounded sample: the top rows of the
+    same frame, sized for ~10-30 s of CPU work."""
+    import oracle
+    H, W = L.shape
+    evals_per_row = W * D
+    # naive cost ~ win^2 byte-ADs per eval; aim at ~2e10 byte-ADs per thread-second-ish total budget
+    budget = 6e9 * threads
+    out_rows = int(max(4, min(H - win, budget / (evals_per_row * win * win))))
+    rows_in = out_rows + win
+    Ls, Rs = L[:rows_in].copy(), R[:rows_in].copy()
+    t0 = time.perf_counter()
+    oracle.literal_mt(Ls, Rs, win, D, 0, threads)
+    dt = time.perf_counter() - t0
+    evals = (rows_in) * W * D      # metric counts full W*H*D of the frame handed in
+    return {"value": round(evals / dt / 1e9, 4), "unit": "Gdisp-evals/s", "cores": threads, "kind": "port",
+            "sample": "oracle.literal_mt on the top %d rows (%d output rows) of the same %dx%d frame, win=%d D=%d, %.1f s"
+                      % (rows_in, out_rows, W, H, win, D, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg3_4k_w15_d128", choices=sorted(WORKLOADS))
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per step per GPU (0 = workload default)")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import opencv_amd as oa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H, win, D, seed, dbg, dfg, pairs = WORKLOADS[args.workload]
+    if args.pairs > 0:
+        pairs = args.pairs
+
+    import oracle                      # input generator + checker + cpu_baseline only
+    Ls, Rs = [], []
+    for i in range(pairs):
+        # distinct pairs per slot and per rank (same generator family as BASELINE.md)
+        Li, Ri = oracle.rds(seed + 7919 * i + 104729 * rank, W, H, dbg, dfg, 0)
+        Ls.append(Li)
+        Rs.append(Ri)
+    dL = torch.from_numpy(np.stack(Ls)).to(dev)
+    dR = torch.from_numpy(np.stack(Rs)).to(dev)
+    dO = torch.empty((pairs, H, W), dtype=torch.uint8, device=dev)
+    ctx = oa.Context(local)
+
+    def step():
+        oa.compute_batch_device(dL, dR, win, D, 0, out=dO, ctx=ctx)
+
+    # bit-exact gate before any timing (rank 0, first pair, a band of rows against the sliding-sum oracle)
+    verified = None
+    if not args.no_verify and rank == 0:
+        step()
+        torch.cuda.synchronize()
+        rows = min(H, 160 + win)
+        exp = oracle.box(Ls[0][:rows], Rs[0][:rows], win, D, 0)
+        got = dO[0, : rows - win].cpu().numpy()
+        verified = bool(np.array_equal(got, exp[: rows - win]))
+        if not verified:
+            raise SystemExit("bench: GPU output differs from the oracle -- refusing to time a wrong kernel")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nl, matcher_ms, prep_ms = ctx.profile_end()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    evals_step = W * H * D * pairs                     # per GPU per step (metric counts full W*H*D)
+    value = evals_step * world * args.steps / dt / 1e9
+    k_ms = matcher_ms / max(nl, 1)                     # matcher kernel, average launch duration (HIP events)
+    alg_bytes = 3.0 * W * H * pairs                    # 2 plane reads + 1 plane write per frame
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    valu_ops = 7.0 * W * H * D * pairs
+    line = {
+        "metric": "Gdisp-evals/sec (WxHxD/s)", "value": round(value, 3), "unit": "Gdisp-evals/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "%s: rds(%d,%d,%d,%d,%d) %dx%d window D=%d, %d pairs/step/GPU, device-resident planes"
+                               % (args.workload, seed, W, H, dbg, dfg, win, win, D, pairs),
+                   "parallelism": "batch-dp%d" % world, "kernel": ctx.last_kernel()},
+        "frames_per_s": round(pairs * world * args.steps / dt, 2),
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "kernel": ctx.last_kernel(), "kernel_ms": round(k_ms, 4), "prep_ms": round(prep_ms / max(nl, 1), 4),
+                     "note": "path is VALU-bound (SURVEY 8d): algorithmic bytes 3*W*H per frame; see valu"},
+        "valu": {"ops_per_eval": 7, "achieved_Tops": round(valu_ops / (k_ms * 1e-3) / 1e12, 3) if k_ms > 0 else 0,
+                 "nominal_peak_Tops": VALU_NOMINAL_TOPS,
+                 "frac": round(valu_ops / (k_ms * 1e-3) / 1e12 / VALU_NOMINAL_TOPS, 4) if k_ms > 0 else 0},
+        "verified_bit_exact": verified,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(Ls[0], Rs[0], win, D, min(os.cpu_count() or 1, 16))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

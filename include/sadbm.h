@@ -83,7 +83,7 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
                             int win, int max_disp, uint32_t flags, sadbm_plane *out);
 
 /* Device-resident getDisparity: dL/dR/dOut are device pointers on ctx's device; asynchronous on
- * `stream` (a hipStream_t passed as void*, NULL = the context's own stream).  channels in {1,3,4}
+ * `stream` (a hipStream_t passed as void*; NULL = the device's default stream, as in HIP).  channels in {1,3,4}
  * (channel 0 is used, SAD.cpp:19-20). */
 int sadbm_compute_device(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_t *dR,
                          int64_t pitchR, int rows, int cols, int channels, int win, int max_disp,
@@ -107,8 +107,12 @@ int sadbm_compute_batch_device(sadbm_ctx *ctx, const uint8_t *dL, const uint8_t 
                                int win, int max_disp, uint32_t flags, uint8_t *dOut,
                                int64_t out_pitch, int64_t pair_stride_out, void *stream);
 
-/* Introspection for benchmarks: name and grid of the kernel the last call on this ctx launched. */
+/* Introspection for benchmarks (no reference counterpart): name of the matcher kernel the last call
+ * on this ctx launched, and HIP-event timing of the matcher launches between profile_begin and
+ * profile_end (events are recorded on the launch stream, nothing synchronises until profile_end). */
 const char *sadbm_last_kernel_name(const sadbm_ctx *ctx);
+int sadbm_profile_begin(sadbm_ctx *ctx, int max_launches);
+int sadbm_profile_end(sadbm_ctx *ctx, int *n_launches, float *matcher_ms_total, float *prep_ms_total);
 
 #ifdef __cplusplus
 }

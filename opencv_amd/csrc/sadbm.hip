@@ -381,6 +381,9 @@ struct sadbm_ctx {
     uint8_t *stage_out;
     size_t stage_out_cap;
     char last_kernel[64];
+    // profiling: event triples (before prep, before matcher, after matcher) per pipeline run
+    hipEvent_t *ev;
+    int ev_cap, ev_n, prof_on;
 };
 
 namespace {
@@ -441,6 +444,9 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     if (rc) return rc;
     uint8_t *pL = ctx->planes, *pR = ctx->planes + plane_bytes * (size_t)n_pairs;
 
+    const bool prof = ctx->prof_on && ctx->ev_n < ctx->ev_cap;
+    hipEvent_t *ev = prof ? ctx->ev + 3 * ctx->ev_n : nullptr;
+    if (prof) HIPCHK(hipEventRecord(ev[0], st));
     dim3 pg((pitch / 4 + 255) / 256, need_rows, n_pairs);
     hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dL, pitchL, pair_stride_in, channels, need_rows, cols, pL, pitch, (int64_t)plane_bytes);
     hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dR, pitchR, pair_stride_in, channels, need_rows, cols, pR, pitch, (int64_t)plane_bytes);
@@ -452,6 +458,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     p.out = dOut; p.out_pitch = out_pitch; p.out_stride = pair_stride_out; p.flags = flags;
     p.dword_store = ((((uintptr_t)dOut) | (uintptr_t)out_pitch | (uintptr_t)pair_stride_out) & 3) == 0;
     p.NQ = 0; p.NCp = 0; p.TY = 0;
+    if (prof) HIPCHK(hipEventRecord(ev[1], st));
 
     if (win > MAXWIN || (flags & SADBM_FORCE_GENERIC)) {
         dim3 g((cols + 255) / 256, nvalid, n_pairs);
@@ -475,6 +482,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_quad_kernel<%d>", win);
     }
     HIPCHK(hipGetLastError());
+    if (prof) { HIPCHK(hipEventRecord(ev[2], st)); ctx->ev_n++; }
     return SADBM_OK;
 }
 
@@ -529,11 +537,51 @@ void sadbm_destroy(sadbm_ctx *c)
     if (c->planes) (void)hipFree(c->planes);
     if (c->stage_in) (void)hipFree(c->stage_in);
     if (c->stage_out) (void)hipFree(c->stage_out);
+    for (int i = 0; i < 3 * c->ev_cap; ++i) (void)hipEventDestroy(c->ev[i]);
+    delete[] c->ev;
     if (g_tls_ctx == c) g_tls_ctx = nullptr;
     delete c;
 }
 
 const char *sadbm_last_kernel_name(const sadbm_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
+
+int sadbm_profile_begin(sadbm_ctx *ctx, int max_launches)
+{
+    if (!ctx) return SADBM_E_NULL;
+    if (max_launches < 1 || max_launches > 65536) return SADBM_E_PARAM;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->ev_cap < max_launches) {
+        hipEvent_t *ne = new (std::nothrow) hipEvent_t[3 * (size_t)max_launches];
+        if (!ne) return SADBM_E_ALLOC;
+        for (int i = 0; i < 3 * ctx->ev_cap; ++i) ne[i] = ctx->ev[i];
+        for (int i = 3 * ctx->ev_cap; i < 3 * max_launches; ++i) {
+            hipError_t e = hipEventCreate(&ne[i]);
+            if (e != hipSuccess) { for (int j = 3 * ctx->ev_cap; j < i; ++j) (void)hipEventDestroy(ne[j]); delete[] ne; return hip_fail(e, "hipEventCreate"); }
+        }
+        delete[] ctx->ev;
+        ctx->ev = ne; ctx->ev_cap = max_launches;
+    }
+    ctx->ev_n = 0; ctx->prof_on = 1;
+    return SADBM_OK;
+}
+
+int sadbm_profile_end(sadbm_ctx *ctx, int *n_launches, float *matcher_ms_total, float *prep_ms_total)
+{
+    if (!ctx) return SADBM_E_NULL;
+    ctx->prof_on = 0;
+    float mt = 0.f, pt = 0.f;
+    for (int i = 0; i < ctx->ev_n; ++i) {
+        float a = 0.f, b = 0.f;
+        HIPCHK(hipEventSynchronize(ctx->ev[3 * i + 2]));
+        HIPCHK(hipEventElapsedTime(&a, ctx->ev[3 * i], ctx->ev[3 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&b, ctx->ev[3 * i + 1], ctx->ev[3 * i + 2]));
+        pt += a; mt += b;
+    }
+    if (n_launches) *n_launches = ctx->ev_n;
+    if (matcher_ms_total) *matcher_ms_total = mt;
+    if (prep_ms_total) *prep_ms_total = pt;
+    return SADBM_OK;
+}
 
 int sadbm_compute_band_device(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_t *dR, int64_t pitchR,
                               int frame_rows, int row0, int rows_in, int rows_out, int cols, int channels, int win,
@@ -551,7 +599,7 @@ int sadbm_compute_band_device(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL,
     if (nvalid < 0) nvalid = 0;
     if (cols - win <= 0) nvalid = 0;
     if (nvalid > 0 && rows_in < nvalid + win - 1) return SADBM_E_SIZE;
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t st = (hipStream_t)stream;   // NULL = the device's default stream, as in HIP
     return run_pipeline(ctx, dL, pitchL, dR, pitchR, 0, 1, rows_in, rows_out, nvalid, cols, channels, win, max_disp, flags,
                         dOut, out_pitch, 0, st);
 }
@@ -579,7 +627,7 @@ int sadbm_compute_batch_device(sadbm_ctx *ctx, const uint8_t *dL, const uint8_t 
     if (n_pairs > 1 && (pair_stride_in < pitch_in * (int64_t)rows || pair_stride_out < out_pitch * (int64_t)rows)) return SADBM_E_SIZE;
     int nvalid = rows - win;
     if (nvalid < 0 || cols - win <= 0) nvalid = 0;
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t st = (hipStream_t)stream;   // NULL = the device's default stream, as in HIP
     // grid.z carries the pair index (<= 65535 per launch)
     for (int n0 = 0; n0 < n_pairs; n0 += 32768) {
         int nn = n_pairs - n0 < 32768 ? n_pairs - n0 : 32768;

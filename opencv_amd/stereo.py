@@ -62,6 +62,13 @@ def load_library():
     if not os.path.exists(_SO):
         raise SadbmError(-100, "libsadbm.so not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                                "there is no CPU fallback")
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same soname as
+    # /opt/rocm's).  Import torch first so libsadbm.so binds to the runtime torch uses -- device
+    # pointers and streams are then shared between the two; two runtimes would each see no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(_SO)
     vp, i32, i64, u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint32
     L.sadbm_version.restype = i32
@@ -78,7 +85,9 @@ def load_library():
     L.sadbm_compute_batch_device.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, u32, vp, i64, i64, vp]
     L.sadbm_last_kernel_name.argtypes = [vp]
     L.sadbm_last_kernel_name.restype = ctypes.c_char_p
-    for name in ("sadbm_create", "sadbm_get_disparity", "sadbm_get_disparity_ctx", "sadbm_compute_device",
+    L.sadbm_profile_begin.argtypes = [vp, i32]
+    L.sadbm_profile_end.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    for name in ("sadbm_profile_begin", "sadbm_profile_end", "sadbm_create", "sadbm_get_disparity", "sadbm_get_disparity_ctx", "sadbm_compute_device",
                  "sadbm_compute_band_device", "sadbm_compute_batch_device"):
         getattr(L, name).restype = i32
     _lib = L
@@ -118,6 +127,17 @@ class Context:
     @property
     def handle(self):
         return self._h
+
+    def profile_begin(self, max_launches=1024):
+        _check(load_library().sadbm_profile_begin(self._h, int(max_launches)))
+
+    def profile_end(self):
+        """(n_launches, matcher_ms_total, prep_ms_total) -- HIP events around the kernels."""
+        n = ctypes.c_int(0)
+        m = ctypes.c_float(0)
+        p = ctypes.c_float(0)
+        _check(load_library().sadbm_profile_end(self._h, ctypes.byref(n), ctypes.byref(m), ctypes.byref(p)))
+        return n.value, m.value, p.value
 
     def last_kernel(self):
         return load_library().sadbm_last_kernel_name(self._h).decode()

@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3_4k_w15_d128", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="pairs per step per GPU (0 = workload default)")
+    ap.add_argument("--flags", type=int, default=0, help="SADBM_* flag bits (4 = L1-operand matcher variant)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -94,7 +95,7 @@ def main():
     ctx = oa.Context(local)
 
     def step():
-        oa.compute_batch_device(dL, dR, win, D, 0, out=dO, ctx=ctx)
+        oa.compute_batch_device(dL, dR, win, D, args.flags, out=dO, ctx=ctx)
 
     # bit-exact gate before any timing (rank 0, first pair, a band of rows against the sliding-sum oracle)
     verified = None

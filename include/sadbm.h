@@ -33,6 +33,7 @@ extern "C" {
 /* flags */
 #define SADBM_RAW_LOC        1u   /* write loc (0..max_disp-1) instead of (loc*16)&255; needs max_disp<=256 */
 #define SADBM_FORCE_GENERIC  2u   /* use the brute-force HIP kernel (any win); for cross-checks */
+#define SADBM_KERNEL_GLOBAL  4u   /* use the matcher variant that reads operands through L1 instead of LDS (A/B) */
 
 /* error codes */
 #define SADBM_OK        0

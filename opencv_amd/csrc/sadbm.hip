@@ -31,9 +31,22 @@
 
 namespace {
 
-constexpr int PADL = 256;     // >= max_disp-1 + slack; keeps x0-k >= -PADL for every disparity
+constexpr int PADL = 320;     // >= 256 + 3 + slack; keeps every R read at x0-k-3 >= -PADL addressable
 constexpr int PADR = 64;      // >= 4*NW + 8 for the widest window
-constexpr int KC = 16;        // disparities per thread
+#ifndef SADBM_KC
+#define SADBM_KC 16
+#endif
+#ifndef SADBM_FUSED_STEP
+#define SADBM_FUSED_STEP 0
+#endif
+#ifndef SADBM_TYMAX
+#define SADBM_TYMAX 64
+#endif
+#ifndef SADBM_WPE
+#define SADBM_WPE 2
+#endif
+constexpr int KC = SADBM_KC;  // disparities per thread (multiple of 4)
+constexpr int TMAX = KC / 4;  // disparities per byte-alignment class
 constexpr int MAXWIN = 25;    // widest window with a dedicated instantiation
 constexpr uint32_t KEY_MAX = 0xFFFFFFFFu;
 
@@ -50,6 +63,7 @@ struct Params {
     int win, D;
     int NQ, NCp;              // quads per block, chunk slots per block (NQ*NCp = blockDim.x)
     int TY;                   // output rows per block
+    int LW, RW;               // LDS row segment: L words, R words per shifted copy (sad_quad_lds_kernel)
     uint8_t *out;
     int64_t out_pitch, out_stride;
     uint32_t flags;
@@ -177,22 +191,23 @@ __device__ __forceinline__ void march_step(const uint8_t *Lnew, const uint8_t *R
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         // disparities k0+c+4t, t=0..3 share byte alignment: word j of disparity t is Wn[j - t + 3]
-        uint32_t Wn[NW + 3], Wo[NW + 3];
-        const uint8_t *pn = Rnew + (x0 - k0 - c - 12);
+        constexpr int NR = NW + TMAX - 1;
+        uint32_t Wn[NR], Wo[NR];
+        const uint8_t *pn = Rnew + (x0 - k0 - c - 4 * (TMAX - 1));
 #pragma unroll
-        for (int i = 0; i < NW + 3; ++i) Wn[i] = *(const u32u *)(pn + 4 * i);
+        for (int i = 0; i < NR; ++i) Wn[i] = *(const u32u *)(pn + 4 * i);
         if constexpr (HAS_OLD) {
-            const uint8_t *po = Rold + (x0 - k0 - c - 12);
+            const uint8_t *po = Rold + (x0 - k0 - c - 4 * (TMAX - 1));
 #pragma unroll
-            for (int i = 0; i < NW + 3; ++i) Wo[i] = *(const u32u *)(po + 4 * i);
+            for (int i = 0; i < NR; ++i) Wo[i] = *(const u32u *)(po + 4 * i);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < TMAX; ++t) {
             const int kk = c + 4 * t;
-            const uint32_t *Rn = &Wn[3 - t];
+            const uint32_t *Rn = &Wn[TMAX - 1 - t];
             uint32_t bn0, bn1, bo0 = 0, bo1 = 0;
             row_bases<WIN>(Ln, Rn, bn0, bn1);
-            const uint32_t *Ro = &Wo[3 - t];
+            const uint32_t *Ro = &Wo[TMAX - 1 - t];
             if constexpr (HAS_OLD) row_bases<WIN>(Lo, Ro, bo0, bo1);
 #define SADBM_UPD(A)                                                                        \
             {                                                                               \
@@ -237,7 +252,7 @@ __device__ __forceinline__ void chunk_min(const uint32_t (&C)[KC][4], int k0, in
 }
 
 template <int WIN>
-__global__ void __launch_bounds__(256) sad_quad_kernel(Params p)
+__global__ void __launch_bounds__(256, SADBM_WPE) sad_quad_kernel(Params p)
 {
     using G = Geo<WIN>;
     __shared__ uint4 merge[2][256];
@@ -327,6 +342,202 @@ __global__ void __launch_bounds__(256) sad_quad_kernel(Params p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 2b. the matcher, LDS-staged (default).  Same arithmetic as sad_quad_kernel; the two image rows a
+//     marching step touches are staged once per block in LDS -- the L segment as is, the R segment as
+//     four copies shifted by 0..3 bytes so that every R word a lane needs (byte offset x0-k+4j) is an
+//     ALIGNED dword of copy (k&3) (misaligned ds_read is ~10x slower on gfx950).  The per-lane unaligned
+//     global loads of sad_quad_kernel kept the L1 (TCP) ~94 % busy; LDS serves them conflict-free
+//     (consecutive lanes read consecutive dwords).
+// LDS map (dwords): [merge 2x256x4] then 2 buffers x 2 row slots (new, old) x { L[LW] | R0[RW] R1 R2 R3 }.
+// ---------------------------------------------------------------------------------------------
+template <int WIN, bool SUB>
+__device__ __forceinline__ void march_pass_lds(const uint32_t *row, int lofs, int rofs, int RW, uint32_t (&C)[KC][4])
+{
+    using G = Geo<WIN>;
+    constexpr int NW = G::NW;
+    constexpr int NR = NW + TMAX - 1;
+    uint32_t Lw[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) Lw[j] = row[lofs + j];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint32_t Wr[NR];
+        const uint32_t *pr = row + rofs + c * RW;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) Wr[i] = pr[i];
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            const int kk = c + 4 * t;
+            const uint32_t *Rw = &Wr[TMAX - 1 - t];
+            uint32_t b0, b1;
+            row_bases<WIN>(Lw, Rw, b0, b1);
+            if constexpr (!SUB) {
+                C[kk][0] = row_ends<WIN, 0>(Lw, Rw, C[kk][0]) + base_sel<WIN, 0>(b0, b1);
+                C[kk][1] = row_ends<WIN, 1>(Lw, Rw, C[kk][1]) + base_sel<WIN, 1>(b0, b1);
+                C[kk][2] = row_ends<WIN, 2>(Lw, Rw, C[kk][2]) + base_sel<WIN, 2>(b0, b1);
+                C[kk][3] = row_ends<WIN, 3>(Lw, Rw, C[kk][3]) + base_sel<WIN, 3>(b0, b1);
+            } else {
+                C[kk][0] -= row_ends<WIN, 0>(Lw, Rw, base_sel<WIN, 0>(b0, b1));
+                C[kk][1] -= row_ends<WIN, 1>(Lw, Rw, base_sel<WIN, 1>(b0, b1));
+                C[kk][2] -= row_ends<WIN, 2>(Lw, Rw, base_sel<WIN, 2>(b0, b1));
+                C[kk][3] -= row_ends<WIN, 3>(Lw, Rw, base_sel<WIN, 3>(b0, b1));
+            }
+        }
+    }
+}
+
+// Steady-state step: C += H(new row) - H(old row) with the shared-word sums of both rows folded into
+// one difference per disparity:  C_a = ends_new(acc=C_a) - ends_old(acc = base_old - base_new).
+template <int WIN>
+__device__ __forceinline__ void march_step_lds(const uint32_t *rown, const uint32_t *rowo, int lofs, int rofs, int RW,
+                                               uint32_t (&C)[KC][4])
+{
+    using G = Geo<WIN>;
+    constexpr int NW = G::NW;
+    constexpr int NR = NW + TMAX - 1;
+    uint32_t Ln[NW], Lo[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) { Ln[j] = rown[lofs + j]; Lo[j] = rowo[lofs + j]; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint32_t Wn[NR], Wo[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) { Wn[i] = rown[rofs + c * RW + i]; Wo[i] = rowo[rofs + c * RW + i]; }
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            const int kk = c + 4 * t;
+            const uint32_t *Rn = &Wn[TMAX - 1 - t];
+            const uint32_t *Ro = &Wo[TMAX - 1 - t];
+            uint32_t bn0, bn1, bo0, bo1;
+            row_bases<WIN>(Ln, Rn, bn0, bn1);
+            row_bases<WIN>(Lo, Ro, bo0, bo1);
+            const uint32_t d0 = bo0 - bn0, d1 = bo1 - bn1;
+            C[kk][0] = row_ends<WIN, 0>(Ln, Rn, C[kk][0]) - row_ends<WIN, 0>(Lo, Ro, base_sel<WIN, 0>(d0, d1));
+            C[kk][1] = row_ends<WIN, 1>(Ln, Rn, C[kk][1]) - row_ends<WIN, 1>(Lo, Ro, base_sel<WIN, 1>(d0, d1));
+            C[kk][2] = row_ends<WIN, 2>(Ln, Rn, C[kk][2]) - row_ends<WIN, 2>(Lo, Ro, base_sel<WIN, 2>(d0, d1));
+            C[kk][3] = row_ends<WIN, 3>(Ln, Rn, C[kk][3]) - row_ends<WIN, 3>(Lo, Ro, base_sel<WIN, 3>(d0, d1));
+        }
+    }
+}
+
+template <int WIN>
+__global__ void __launch_bounds__(256, SADBM_WPE) sad_quad_lds_kernel(Params p)
+{
+    using G = Geo<WIN>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint4 *merge = reinterpret_cast<uint4 *>(smem);          // [2][256]
+    uint32_t *rows = smem + 2 * 256 * 4;                      // [2 buffers][2 slots][ROWW]
+
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int q = tid & (p.NQ - 1);
+    const int c = tid / p.NQ;
+    const int xb = blockIdx.x * p.NQ * 4;
+    const int x0 = xb + q * 4;
+    const int k0 = c * KC;
+    const int yb = blockIdx.y * p.TY;
+    const int ny = min(p.TY, p.nvalid - yb);
+    const uint8_t *L = p.L + (int64_t)blockIdx.z * p.plane_stride;
+    const uint8_t *R = p.R + (int64_t)blockIdx.z * p.plane_stride;
+    uint8_t *out = p.out + (int64_t)blockIdx.z * p.out_stride;
+    const int ocols = p.W - p.win;
+    const int LW = p.LW, RW = p.RW, ROWW = LW + 4 * RW;
+    const int PADK = p.NCp * KC;                              // R segment starts at column xb - PADK
+    const int xlim = p.W + PADR - 4;                          // last addressable dword of a padded row
+
+    const int dlim = p.D - 1 - k0;
+    const int kmaxrel0 = x0 - k0;
+    const bool active = (x0 < ocols) && (dlim >= 0) && (kmaxrel0 + 3 >= 0);
+    const bool slow_thread = active && (kmaxrel0 < KC - 1 || dlim < KC - 1);
+    const bool slow = __any(slow_thread);
+    const int lofs = q;
+    const int rofs = LW + q + (PADK - k0) / 4 - (TMAX - 1);
+
+    uint32_t C[KC][4];
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) C[kk][a] = G::HI16 ? (uint32_t)(k0 + kk) : 0u;
+
+    // stage the rows of marching step r into buffer (r & 1): slot 0 = new row yb+r, slot 1 = old row yb+r-WIN
+    auto stage = [&](int r) {
+        uint32_t *dst = rows + (r & 1) * 2 * ROWW;
+        const int nslot = (r >= WIN) ? 2 : 1;
+        for (int idx = tid; idx < nslot * ROWW; idx += nthr) {
+            const int slot = idx >= ROWW;
+            const int w = idx - slot * ROWW;
+            const int64_t ro = (int64_t)(slot ? yb + r - WIN : yb + r) * p.pitch;
+            uint32_t v = 0;
+            if (w < LW) {
+                const int off = xb + 4 * w;
+                if (off <= xlim) v = *(const uint32_t *)(L + ro + off);
+            } else {
+                const int cc = (w - LW) / RW;
+                const int i = (w - LW) - cc * RW;
+                const int off = xb - PADK + 4 * i - cc;
+                if (off <= xlim) v = *(const u32u *)(R + ro + off);
+            }
+            dst[idx] = v;
+        }
+    };
+
+    const int nsteps = WIN - 1 + ny;
+    stage(0);
+    __syncthreads();
+    for (int r = 0; r < nsteps; ++r) {
+        const uint32_t *buf = rows + (r & 1) * 2 * ROWW;
+        if (active) {
+#if SADBM_FUSED_STEP
+            if (r >= WIN) march_step_lds<WIN>(buf, buf + ROWW, lofs, rofs, RW, C);
+            else          march_pass_lds<WIN, false>(buf, lofs, rofs, RW, C);
+#else
+            march_pass_lds<WIN, false>(buf, lofs, rofs, RW, C);
+            if (r >= WIN) march_pass_lds<WIN, true>(buf + ROWW, lofs, rofs, RW, C);
+#endif
+        }
+        if (r + 1 < nsteps) stage(r + 1);                     // other buffer: last read in step r-1
+        const bool emit = r >= WIN - 1;                       // block-uniform
+        uint32_t best[4] = {KEY_MAX, KEY_MAX, KEY_MAX, KEY_MAX};
+        const int par = r & 1;
+        if (emit) {
+            if (active) chunk_min<WIN>(C, k0, kmaxrel0, dlim, slow, best);
+            if (c > 0) merge[par * 256 + tid] = make_uint4(best[0], best[1], best[2], best[3]);
+        }
+        __syncthreads();
+        if (!emit) continue;
+        const int y = yb + r - (WIN - 1);
+        if (c == 0 && x0 < p.W) {
+            for (int cc = 1; cc < p.NCp; ++cc) {
+                uint4 o = merge[par * 256 + cc * p.NQ + q];
+                best[0] = min(best[0], o.x); best[1] = min(best[1], o.y);
+                best[2] = min(best[2], o.z); best[3] = min(best[3], o.w);
+            }
+            uint32_t bytes = 0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int j = x0 + a;
+                uint32_t key = best[a];
+                // SAD.cpp:40,44: slots k>j keep cost 0; the first of them (k=j+1) wins unless a valid
+                // slot has cost 0 (then that smaller k is already the minimum).
+                if (j + 1 < p.D) key = min(key, (uint32_t)(j + 1));
+                uint32_t loc = key & 0xFFu;
+                uint32_t v = (p.flags & SADBM_RAW_LOC) ? loc : ((loc * 16u) & 0xFFu);   // SAD.cpp:57
+                if (j >= ocols) v = 0;
+                bytes |= v << (8 * a);
+            }
+            uint8_t *o = out + (int64_t)y * p.out_pitch + x0;
+            if (p.dword_store && x0 + 3 < p.W) {
+                *(uint32_t *)o = bytes;
+            } else {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    if (x0 + a < p.W) o[a] = (uint8_t)(bytes >> (8 * a));
+            }
+        }
+    }
+}
+
 // Brute-force matcher for any window (win > MAXWIN or SADBM_FORCE_GENERIC): one thread per output
 // pixel, window SAD with v_sad_u8 on bytes from the padded planes.  Correctness path, not tuned.
 __global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
@@ -363,6 +574,12 @@ template <int... I>
 static quad_kernel_t pick_quad_kernel(int win, Seq<I...>)
 {
     static const quad_kernel_t table[] = { sad_quad_kernel<I + 1>... };
+    return table[win - 1];
+}
+template <int... I>
+static quad_kernel_t pick_quad_lds_kernel(int win, Seq<I...>)
+{
+    static const quad_kernel_t table[] = { sad_quad_lds_kernel<I + 1>... };
     return table[win - 1];
 }
 
@@ -457,7 +674,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     p.W = cols; p.nvalid = nvalid; p.win = win; p.D = D;
     p.out = dOut; p.out_pitch = out_pitch; p.out_stride = pair_stride_out; p.flags = flags;
     p.dword_store = ((((uintptr_t)dOut) | (uintptr_t)out_pitch | (uintptr_t)pair_stride_out) & 3) == 0;
-    p.NQ = 0; p.NCp = 0; p.TY = 0;
+    p.NQ = 0; p.NCp = 0; p.TY = 0; p.LW = 0; p.RW = 0;
     if (prof) HIPCHK(hipEventRecord(ev[1], st));
 
     if (win > MAXWIN || (flags & SADBM_FORCE_GENERIC)) {
@@ -465,7 +682,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         hipLaunchKernelGGL(sad_generic_kernel, g, dim3(256), 0, st, p);
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_generic_kernel");
     } else {
-        const int NC = (D + KC - 1) / KC;                     // <= 16
+        const int NC = (D + KC - 1) / KC;                     // <= 256/KC
         p.NCp = pow2ceil(NC);
         const int quads = (cols + 3) / 4;
         p.NQ = 256 / p.NCp;
@@ -473,13 +690,23 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         const int bx = (quads + p.NQ - 1) / p.NQ;
         // rows per block: long bands amortise the win-1 warm-up rows; shorten them until the grid
         // has a few blocks per CU.
-        int TY = 64;
+        int TY = SADBM_TYMAX;
         while (TY > 16 && (long)bx * ((nvalid + TY - 1) / TY) * n_pairs < 1024) TY >>= 1;
         p.TY = TY;
         dim3 g(bx, (nvalid + TY - 1) / TY, n_pairs);
-        quad_kernel_t k = pick_quad_kernel(win, MakeSeq<MAXWIN>::type());
-        hipLaunchKernelGGL(k, g, dim3(p.NQ * p.NCp), 0, st, p);
-        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_quad_kernel<%d>", win);
+        if (flags & SADBM_KERNEL_GLOBAL) {
+            quad_kernel_t k = pick_quad_kernel(win, MakeSeq<MAXWIN>::type());
+            hipLaunchKernelGGL(k, g, dim3(p.NQ * p.NCp), 0, st, p);
+            snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_quad_kernel<%d>", win);
+        } else {
+            const int NW = (win + 6) / 4;
+            p.LW = p.NQ + NW;
+            p.RW = p.NQ + NW + p.NCp * KC / 4 + 1;
+            const size_t lds = (size_t)(2 * 256 * 4 + 4 * (p.LW + 4 * p.RW)) * 4;
+            quad_kernel_t k = pick_quad_lds_kernel(win, MakeSeq<MAXWIN>::type());
+            hipLaunchKernelGGL(k, g, dim3(p.NQ * p.NCp), lds, st, p);
+            snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_quad_lds_kernel<%d>", win);
+        }
     }
     HIPCHK(hipGetLastError());
     if (prof) { HIPCHK(hipEventRecord(ev[2], st)); ctx->ev_n++; }

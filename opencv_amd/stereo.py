@@ -14,12 +14,13 @@ import numpy as np
 
 RAW_LOC = 1
 FORCE_GENERIC = 2
+KERNEL_GLOBAL = 4
 DEFAULT_WIN_SIZE = 7     # SAD.cpp:9
 DEFAULT_DSR = 30         # SAD.cpp:11
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SO = os.path.join(_CSRC, "libsadbm.so")
+_SO = os.environ.get("SADBM_LIB") or os.path.join(_CSRC, "libsadbm.so")   # SADBM_LIB: experiment builds
 _lib = None
 
 

@@ -53,6 +53,8 @@ def test_sweep_matches_oracle(win, D):
         exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
         got = oa.get_disparity_host(L, R, win, D, oa.RAW_LOC)
         assert np.array_equal(got, exp), (win, D, binary, np.argwhere(got != exp)[:5])
+        got = oa.get_disparity_host(L, R, win, D, oa.RAW_LOC | oa.KERNEL_GLOBAL)     # L1-operand variant
+        assert np.array_equal(got, exp), ("global", win, D, binary, np.argwhere(got != exp)[:5])
 
 
 @pytest.mark.parametrize("shape", [(9, 300), (300, 9), (40, 17), (8, 8), (7, 50), (50, 7), (1, 1), (33, 129)])

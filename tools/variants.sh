@@ -1,0 +1,8 @@
+#!/bin/bash
+# Runs bench.py once per experiment build (opencv_amd/csrc/libsadbm_*.so); prints value + kernel ms.
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+WL=${1:-cfg3_4k_w15_d128}
+for so in $ROOT/opencv_amd/csrc/libsadbm*.so; do
+  r=$(SADBM_LIB=$so timeout -k 10 120 python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu --workload $WL 2>/dev/null) || { echo "$(basename $so) FAILED"; continue; }
+  echo "$(basename $so) $(echo $r | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["roofline"]["kernel_ms"], d["verified_bit_exact"])')"
+done

@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--workload", default="cfg3_4k_w15_d128", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="pairs per step per GPU (0 = workload default)")
     ap.add_argument("--flags", type=int, default=0, help="SADBM_* flag bits (4 = L1-operand matcher variant)")
+    ap.add_argument("--split", default="batch", choices=["batch", "bands"],
+                    help="batch: every rank its own pairs, no collective (weak scaling); bands: ONE frame split into "
+                         "row bands + one RCCL all-gather per frame (strong scaling, BASELINE config 4)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -89,13 +92,29 @@ def main():
         Li, Ri = oracle.rds(seed + 7919 * i + 104729 * rank, W, H, dbg, dfg, 0)
         Ls.append(Li)
         Rs.append(Ri)
-    dL = torch.from_numpy(np.stack(Ls)).to(dev)
-    dR = torch.from_numpy(np.stack(Rs)).to(dev)
-    dO = torch.empty((pairs, H, W), dtype=torch.uint8, device=dev)
     ctx = oa.Context(local)
+    bands = args.split == "bands"
+    if bands:
+        # one frame (seed without the rank term so all ranks split the SAME frame); rank keeps band + halo only
+        pairs = 1
+        Lf, Rf = oracle.rds(seed, W, H, dbg, dfg, 0)
+        Ls, Rs = [Lf], [Rf]
+        (r0, r1, per), lb, rb = oa.scatter_band(torch.from_numpy(Lf), torch.from_numpy(Rf), rank, world, win)
+        dLb, dRb = lb.contiguous().to(dev), rb.contiguous().to(dev)
+        full = [None]
 
-    def step():
-        oa.compute_batch_device(dL, dR, win, D, args.flags, out=dO, ctx=ctx)
+        def compute_band(lbt, rbt, frame_rows, row0, rows_out, w, d, flags, out):
+            return oa.compute_band_device(lbt, rbt, frame_rows, row0, rows_out, w, d, flags, out=out, ctx=ctx)
+
+        def step():
+            full[0] = oa.disparity_row_bands(dLb, dRb, H, win, D, rank, world, flags=args.flags, compute_band=compute_band)
+    else:
+        dL = torch.from_numpy(np.stack(Ls)).to(dev)
+        dR = torch.from_numpy(np.stack(Rs)).to(dev)
+        dO = torch.empty((pairs, H, W), dtype=torch.uint8, device=dev)
+
+        def step():
+            oa.compute_batch_device(dL, dR, win, D, args.flags, out=dO, ctx=ctx)
 
     # bit-exact gate before any timing (rank 0, first pair, a band of rows against the sliding-sum oracle)
     verified = None
@@ -104,7 +123,7 @@ def main():
         torch.cuda.synchronize()
         rows = min(H, 160 + win)
         exp = oracle.box(Ls[0][:rows], Rs[0][:rows], win, D, 0)
-        got = dO[0, : rows - win].cpu().numpy()
+        got = (full[0] if bands else dO[0])[: rows - win].cpu().numpy()
         verified = bool(np.array_equal(got, exp[: rows - win]))
         if not verified:
             raise SystemExit("bench: GPU output differs from the oracle -- refusing to time a wrong kernel")
@@ -131,21 +150,35 @@ def main():
         dt = float(t.item())
 
     evals_step = W * H * D * pairs                     # per GPU per step (metric counts full W*H*D)
-    value = evals_step * world * args.steps / dt / 1e9
+    if bands:
+        value = evals_step * args.steps / dt / 1e9     # one frame per step for the whole job
+    else:
+        value = evals_step * world * args.steps / dt / 1e9
     k_ms = matcher_ms / max(nl, 1)                     # matcher kernel, average launch duration (HIP events)
-    alg_bytes = 3.0 * W * H * pairs                    # 2 plane reads + 1 plane write per frame
+    frac_rows = (r1 - r0) / H if bands else 1.0        # a band launch processes its share of the frame
+    alg_bytes = 3.0 * W * H * pairs * frac_rows        # 2 plane reads + 1 plane write per frame
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    valu_ops = 7.0 * W * H * D * pairs
+    valu_ops = 7.0 * W * H * D * pairs * frac_rows
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tj = json.load(f)
+        ent = tj.get("%s|%s|pairs=%d" % (args.workload, ctx.last_kernel(), pairs))
+        if ent and not bands:
+            traffic = ent["hbm_bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
     line = {
         "metric": "Gdisp-evals/sec (WxHxD/s)", "value": round(value, 3), "unit": "Gdisp-evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%s: rds(%d,%d,%d,%d,%d) %dx%d window D=%d, %d pairs/step/GPU, device-resident planes"
                                % (args.workload, seed, W, H, dbg, dfg, win, win, D, pairs),
-                   "parallelism": "batch-dp%d" % world, "kernel": ctx.last_kernel()},
-        "frames_per_s": round(pairs * world * args.steps / dt, 2),
+                   "parallelism": ("row-bands%d+allgather" if bands else "batch-dp%d") % world, "kernel": ctx.last_kernel()},
+        "frames_per_s": round((1 if bands else pairs * world) * args.steps / dt, 2),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "algorithmic_bytes": alg_bytes,
                      "kernel": ctx.last_kernel(), "kernel_ms": round(k_ms, 4), "prep_ms": round(prep_ms / max(nl, 1), 4),
                      "note": "path is VALU-bound (SURVEY 8d): algorithmic bytes 3*W*H per frame; see valu"},
         "valu": {"ops_per_eval": 7, "achieved_Tops": round(valu_ops / (k_ms * 1e-3) / 1e12, 3) if k_ms > 0 else 0,

@@ -10,3 +10,4 @@ from .stereo import (  # noqa: F401
     DEFAULT_WIN_SIZE, DEFAULT_DSR,
 )
 from .bands import band_ranges, band_input_rows  # noqa: F401
+from .multi import shard_pairs, scatter_band, disparity_row_bands  # noqa: F401

@@ -1,0 +1,50 @@
+"""Multi-GPU host logic: one process per GPU, torch.distributed (RCCL).
+
+Two ways the path shards, both without any cost-volume exchange:
+  * batch data parallelism  -- pairs are independent; rank r takes pairs r, r+world, ... ; no collective.
+  * row bands of one frame  -- rank r computes output rows [r*per, (r+1)*per) from input rows
+    [r0, min(r1+win-1, H)) (downward halo only: the window is anchored top-left, SAD.cpp:39), then ONE
+    all-gather of equal-sized u8 bands assembles the full disparity map on every rank.
+
+`compute_band` is the per-rank compute function; the default is the HIP path
+(opencv_amd.compute_band_device).  Tests on CPU pass a checker-backed callable to exercise the
+partition + collective logic with the gloo backend.
+"""
+from .bands import band_input_rows, band_ranges
+
+
+def shard_pairs(n_pairs, rank, world):
+    """Indices of the stereo pairs rank `rank` processes (round-robin; no data-path collective)."""
+    return list(range(rank, n_pairs, world))
+
+
+def scatter_band(frame_left, frame_right, rank, world, win):
+    """Slice (views) of the frame rows rank `rank` needs: its band plus the win-1 row downward halo."""
+    rows = frame_left.shape[0]
+    per, ranges = band_ranges(rows, world)
+    r0, r1 = ranges[rank]
+    i0, i1 = band_input_rows(r0, r1, rows, win)
+    return (r0, r1, per), frame_left[i0:i1], frame_right[i0:i1]
+
+
+def disparity_row_bands(left_band, right_band, frame_rows, win, max_disp, rank, world, group=None, flags=0,
+                        compute_band=None):
+    """Band compute + one all-gather.  left_band/right_band: this rank's input rows (band + halo) as
+    torch uint8 tensors on the rank's device.  Returns the full frame_rows x cols disparity map
+    (identical on every rank)."""
+    import torch
+    import torch.distributed as dist
+    if compute_band is None:
+        from .stereo import compute_band_device as compute_band
+    cols = left_band.shape[1]
+    per, ranges = band_ranges(frame_rows, world)
+    r0, r1 = ranges[rank]
+    # equal counts for the all-gather: every rank contributes `per` rows (short/empty bands are zero-padded)
+    send = torch.zeros((per, cols), dtype=torch.uint8, device=left_band.device)
+    if r1 > r0:
+        compute_band(left_band, right_band, frame_rows, r0, r1 - r0, win, max_disp, flags, out=send[: r1 - r0])
+    if world == 1:
+        return send[:frame_rows]
+    full = torch.empty((world * per, cols), dtype=torch.uint8, device=left_band.device)
+    dist.all_gather_into_tensor(full, send, group=group)
+    return full[:frame_rows]

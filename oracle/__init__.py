@@ -5,5 +5,5 @@ The shipped path (opencv_amd/) never does.  See oracle/sad_oracle.c for the pari
 ("parity unpinned by the reference": the reference has no tests for this path).
 """
 from .oracle import (  # noqa: F401
-    RAW_LOC, build, lib, literal, literal_rows, literal_mt, box, rds, splitmix64, numpy_restatement,
+    RAW_LOC, build, lib, literal, literal_rows, literal_mt, band, box, rds, splitmix64, numpy_restatement,
 )

@@ -40,6 +40,8 @@ def lib():
         L.sad_oracle_box.argtypes = common + [_int]
         for f in (L.sad_oracle_literal, L.sad_oracle_literal_rows, L.sad_oracle_literal_mt, L.sad_oracle_box):
             f.restype = _int
+        L.sad_oracle_band.argtypes = [_u8p, _i64, _u8p, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _u32, _u8p, _i64]
+        L.sad_oracle_band.restype = _int
         L.sad_oracle_rds.argtypes = [ctypes.c_uint64, _int, _int, _int, _int, _int, _u8p, _u8p]
         L.sad_oracle_rds.restype = _int
         L.sad_oracle_splitmix64.argtypes = [ctypes.c_uint64, _int]
@@ -79,6 +81,18 @@ def literal(left, right, win=7, dsr=30, flags=0):
 
 def literal_rows(left, right, win, dsr, row0, row1, flags=0):
     return _call(lib().sad_oracle_literal_rows, left, right, win, dsr, flags, (row0, row1), out_rows=row1 - row0)
+
+
+def band(left_band, right_band, frame_rows, row0, rows_out, win, dsr, flags=0):
+    """Checker twin of sadbm_compute_band_device (input rows [row0, row0+len(left_band)))."""
+    lb, rb = _views(left_band, right_band)
+    rows_in, cols, ch = lb.shape
+    out = np.empty((rows_out, cols), dtype=np.uint8)
+    rc = lib().sad_oracle_band(lb.ctypes.data, lb.strides[0], rb.ctypes.data, rb.strides[0], frame_rows, row0, rows_in,
+                               rows_out, cols, ch, win, dsr, flags, out.ctypes.data, max(cols, 1))
+    if rc != 0:
+        raise ValueError("sad_oracle error %d" % rc)
+    return out
 
 
 def literal_mt(left, right, win=7, dsr=30, flags=0, threads=None):

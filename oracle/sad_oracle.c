@@ -107,6 +107,28 @@ int sad_oracle_literal_rows(const uint8_t *L, int64_t lstep, const uint8_t *R, i
     return 0;
 }
 
+/* Row band of a larger frame, mirroring sadbm_compute_band_device: the buffers hold input rows
+ * [row0, row0+rows_in) of a frame with frame_rows rows; output rows [row0, row0+rows_out) are
+ * produced with SAD.cpp:34's bound evaluated on the frame row index. */
+int sad_oracle_band(const uint8_t *L, int64_t lstep, const uint8_t *R, int64_t rstep, int frame_rows,
+                    int row0, int rows_in, int rows_out, int cols, int ch, int win, int dsr,
+                    uint32_t flags, uint8_t *out, int64_t ostep)
+{
+    int e = oracle_check(L, R, frame_rows, cols, ch, win, dsr, flags, out);
+    if (e) return e;
+    if (row0 < 0 || rows_in < 0 || rows_out < 0 || row0 + rows_out > frame_rows || row0 + rows_in > frame_rows) return -3;
+    int nvalid = frame_rows - win - row0;
+    if (nvalid > rows_out) nvalid = rows_out;
+    if (nvalid < 0) nvalid = 0;
+    if (nvalid > 0 && rows_in < nvalid + win - 1) return -3;
+    /* run the literal loop on a virtual image of nvalid+win rows: its own bound i < rows-win then
+     * admits exactly the nvalid rows; row nvalid+win-1 is never read (SAD.cpp:34 leaves one spare row). */
+    for (int i = 0; i < rows_out; ++i) memset(out + (int64_t)i * ostep, 0, (size_t)cols);
+    if (nvalid > 0)
+        oracle_rows(L, lstep, R, rstep, nvalid + win, cols, ch, win, dsr, flags, out, ostep, 0, nvalid);
+    return 0;
+}
+
 /* Literal restatement with the output rows spread over `threads` OpenMP threads. */
 int sad_oracle_literal_mt(const uint8_t *L, int64_t lstep, const uint8_t *R, int64_t rstep,
                           int rows, int cols, int ch, int win, int dsr, uint32_t flags,

@@ -156,3 +156,37 @@ def test_full_size_1080p_config2_against_box_oracle():
     assert np.array_equal(got, exp)
     # size-independent property: interior of background/foreground recovers the planted disparities
     assert (got[100, 100:300] == 8).all() and (got[500, 700:1100] == 40).all()
+
+
+def test_disparity_row_bands_world1_uses_hip_band_path():
+    """The band + all-gather host function on one GPU (world=1): same code as the N-GPU path minus the
+    collective; the 2-rank collective itself is covered on CPU with gloo (tests/test_multi_cpu.py)."""
+    H, W, win, D = 97, 150, 15, 48
+    L, R = noise_pair(5, H, W, shift=6)
+    (r0, r1, per), lb, rb = oa.scatter_band(dev(L), dev(R), 0, 1, win)
+    full = oa.disparity_row_bands(lb, rb, H, win, D, 0, 1)
+    assert np.array_equal(full.cpu().numpy(), oracle.box(L, R, win, D))
+
+
+def test_cfg4_band_geometry_matches_oracle():
+    """BASELINE config 4 geometry: 4320 rows, 21x21, D=256, 8 bands of 540 rows + 20-row downward halo
+    (column crop 1024 to keep the checker fast).  Band 3 (interior) and band 7 (holds the zero frame)."""
+    H, W, win, D = 4320, 1024, 21, 256
+    L, R = oracle.rds(4, W, H, 32, 200, 0)
+    per, ranges = oa.band_ranges(H, 8)
+    assert per == 540
+    for b in (3, 7):
+        r0, r1 = ranges[b]
+        i0, i1 = oa.band_input_rows(r0, r1, H, win)
+        assert i1 - i0 == (560 if b == 3 else 540)
+        got = oa.compute_band_device(dev(L[i0:i1]), dev(R[i0:i1]), H, r0, r1 - r0, win, D).cpu().numpy()
+        nvalid = min(r1 - r0, H - win - r0)
+        # sliding-sum oracle on the band's rows; one spare row appended so its own i < rows-win bound
+        # (SAD.cpp:34) admits every row the halo supports
+        pad = np.zeros((1, W), np.uint8)
+        Lb = np.concatenate([L[i0:i1], pad]) if b == 3 else L[i0:i1]
+        Rb = np.concatenate([R[i0:i1], pad]) if b == 3 else R[i0:i1]
+        exp = oracle.box(Lb, Rb, win, D)[: r1 - r0]
+        assert np.array_equal(got, exp), b
+        if b == 7:
+            assert nvalid == 540 - 21 and not got[nvalid:].any()

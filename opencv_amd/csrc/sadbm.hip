@@ -39,6 +39,9 @@ constexpr int PADR = 64;      // >= 4*NW + 8 for the widest window
 #ifndef SADBM_FUSED_STEP
 #define SADBM_FUSED_STEP 0
 #endif
+#ifndef SADBM_MERGE_ENDS
+#define SADBM_MERGE_ENDS 1
+#endif
 #ifndef SADBM_TYMAX
 #define SADBM_TYMAX 64
 #endif
@@ -114,6 +117,24 @@ struct Geo {
     static constexpr bool shared_all(int j) { return full(j, 0) && full(j, 1) && full(j, 2) && full(j, 3); }
     // word j is inside the windows of a >= 1..3 but not a = 0 (at most one such j >= 1 exists)
     static constexpr bool shared_hi(int j) { return j >= 1 && full(j, 3) && !full(j, 0); }
+    static constexpr int popc(uint32_t m) { int n = 0; for (int b = 0; b < 4; ++b) n += (m >> (8 * b)) & 1; return n; }
+    static constexpr bool partial(int j, int a) { return mask(j, a) != 0 && !full(j, a); }
+    static constexpr int npartial(int a) { int n = 0; for (int j = 0; j < NW; ++j) n += partial(j, a); return n; }
+    static constexpr int partial_j(int a, int idx)       // idx-th partial word of alignment a, or -1
+    {
+        for (int j = 0; j < NW; ++j) if (partial(j, a)) { if (idx == 0) return j; --idx; }
+        return -1;
+    }
+    // v_perm_b32 selector: in-mask bytes of the low source (word j1) first, then those of the high source
+    // (word j2), remaining bytes constant 0x00 (selector 0x0c)
+    static constexpr uint32_t perm_sel(uint32_t m1, uint32_t m2)
+    {
+        uint32_t sel = 0; int n = 0;
+        for (int b = 0; b < 4; ++b) if ((m1 >> (8 * b)) & 1) sel |= (uint32_t)b << (8 * n++);
+        for (int b = 0; b < 4; ++b) if ((m2 >> (8 * b)) & 1) sel |= (uint32_t)(4 + b) << (8 * n++);
+        for (; n < 4; ++n) sel |= 0x0cu << (8 * n);
+        return sel;
+    }
     static constexpr bool use_hi(int a)
     {
         for (int j = 0; j < NW; ++j) if (shared_hi(j) && full(j, a)) return true;
@@ -149,15 +170,26 @@ template <int WIN, int A>
 __device__ __forceinline__ uint32_t row_ends(const uint32_t (&Lw)[Geo<WIN>::NW], const uint32_t *Rw, uint32_t acc)
 {
     using G = Geo<WIN>;
+    // Ragged window ends.  When the window of column x0+A has a partial word at both ends and together
+    // they hold <= 4 bytes (WIN = 3 mod 4), one v_perm_b32 per image packs both into a single word, so
+    // the pair costs perm + sad instead of 2 x (and + sad); the L-side perm is loop-invariant in k.
+    constexpr int j1 = G::partial_j(A, 0), j2 = G::partial_j(A, 1);
+    constexpr bool merge = SADBM_MERGE_ENDS && G::npartial(A) == 2 &&
+                           (G::popc(G::mask(j1 < 0 ? 0 : j1, A)) + G::popc(G::mask(j2 < 0 ? 0 : j2, A)) <= 4);
 #pragma unroll
     for (int j = 0; j < G::NW; ++j) {
-        constexpr int dummy = 0; (void)dummy;
         const uint32_t m = G::mask(j, A);
         if (G::shared_all(j)) continue;
         if (G::shared_hi(j) && G::full(j, A)) continue;
         if (m == 0) continue;
         if (m == 0xFFFFFFFFu) acc = sad_acc<G::HI16>(Lw[j], Rw[j], acc);
-        else                  acc = sad_acc<G::HI16>(Lw[j] & m, Rw[j] & m, acc);
+        else if (!merge)      acc = sad_acc<G::HI16>(Lw[j] & m, Rw[j] & m, acc);
+    }
+    if constexpr (merge) {
+        constexpr uint32_t sel = G::perm_sel(G::mask(j1, A), G::mask(j2, A));
+        const uint32_t a = __builtin_amdgcn_perm(Lw[j2], Lw[j1], sel);
+        const uint32_t b = __builtin_amdgcn_perm(Rw[j2], Rw[j1], sel);
+        acc = sad_acc<G::HI16>(a, b, acc);
     }
     return acc;
 }

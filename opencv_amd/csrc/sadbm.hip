@@ -39,6 +39,9 @@ constexpr int PADR = 64;      // >= 4*NW + 8 for the widest window
 #ifndef SADBM_FUSED_STEP
 #define SADBM_FUSED_STEP 0
 #endif
+#ifndef SADBM_WPE_LDS
+#define SADBM_WPE_LDS 4
+#endif
 #ifndef SADBM_MERGE_ENDS
 #define SADBM_MERGE_ENDS 1
 #endif
@@ -454,7 +457,7 @@ __device__ __forceinline__ void march_step_lds(const uint32_t *rown, const uint3
 }
 
 template <int WIN>
-__global__ void __launch_bounds__(256, SADBM_WPE) sad_quad_lds_kernel(Params p)
+__global__ void __launch_bounds__(256, (WIN <= 16 ? SADBM_WPE_LDS : 3)) sad_quad_lds_kernel(Params p)
 {
     using G = Geo<WIN>;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -492,25 +495,48 @@ __global__ void __launch_bounds__(256, SADBM_WPE) sad_quad_lds_kernel(Params p)
 #pragma unroll
         for (int a = 0; a < 4; ++a) C[kk][a] = G::HI16 ? (uint32_t)(k0 + kk) : 0u;
 
+    // Staging descriptors, computed once: element e of this thread is LDS word tid + e*nthr of a row slot
+    // and comes from byte offset goff[e] of the row (relative to the L plane; R elements carry R - L).
+    // G_NONE marks a word beyond the padded row (kept zero).
+    constexpr int STG = 6;                                    // >= ceil(ROWW / blockDim) for every geometry
+    constexpr int G_NONE = INT32_MIN, G_RBIT = 1 << 24;       // offsets lie in (-2^20, 2^20)
+    int goff[STG];                                            // (byte offset + 2^20) | G_RBIT for R elements
+#pragma unroll
+    for (int e = 0; e < STG; ++e) {
+        const int w = tid + e * nthr;
+        int g = G_NONE;
+        if (w < LW) {
+            const int off = xb + 4 * w;
+            if (off <= xlim) g = off + (1 << 20);
+        } else if (w < ROWW) {
+            const int cc = (w - LW) / RW;
+            const int i = (w - LW) - cc * RW;
+            const int off = xb - PADK + 4 * i - cc;
+            if (off <= xlim) g = (off + (1 << 20)) | G_RBIT;
+        }
+        goff[e] = g;
+    }
     // stage the rows of marching step r into buffer (r & 1): slot 0 = new row yb+r, slot 1 = old row yb+r-WIN
     auto stage = [&](int r) {
         uint32_t *dst = rows + (r & 1) * 2 * ROWW;
-        const int nslot = (r >= WIN) ? 2 : 1;
-        for (int idx = tid; idx < nslot * ROWW; idx += nthr) {
-            const int slot = idx >= ROWW;
-            const int w = idx - slot * ROWW;
-            const int64_t ro = (int64_t)(slot ? yb + r - WIN : yb + r) * p.pitch;
-            uint32_t v = 0;
-            if (w < LW) {
-                const int off = xb + 4 * w;
-                if (off <= xlim) v = *(const uint32_t *)(L + ro + off);
-            } else {
-                const int cc = (w - LW) / RW;
-                const int i = (w - LW) - cc * RW;
-                const int off = xb - PADK + 4 * i - cc;
-                if (off <= xlim) v = *(const u32u *)(R + ro + off);
+        const int64_t rn = (int64_t)(yb + r) * p.pitch - (1 << 20);
+        const int64_t ro = (int64_t)(yb + r - WIN) * p.pitch - (1 << 20);
+        const bool has_old = r >= WIN;
+#pragma unroll
+        for (int e = 0; e < STG; ++e) {
+            const int w = tid + e * nthr;
+            if (w < ROWW) {
+                const int g = goff[e];
+                uint32_t vn = 0, vo = 0;
+                if (g != G_NONE) {
+                    const uint8_t *base = (g & G_RBIT) ? R : L;
+                    const int o = g & (G_RBIT - 1);
+                    vn = *(const u32u *)(base + rn + o);
+                    if (has_old) vo = *(const u32u *)(base + ro + o);
+                }
+                dst[w] = vn;
+                if (has_old) dst[ROWW + w] = vo;
             }
-            dst[idx] = v;
         }
     };
 

@@ -384,21 +384,21 @@ __global__ void __launch_bounds__(256, SADBM_WPE) sad_quad_kernel(Params p)
 //     ALIGNED dword of copy (k&3) (misaligned ds_read is ~10x slower on gfx950).  The per-lane unaligned
 //     global loads of sad_quad_kernel kept the L1 (TCP) ~94 % busy; LDS serves them conflict-free
 //     (consecutive lanes read consecutive dwords).
-// LDS map (dwords): [merge 2x256x4] then 2 buffers x 2 row slots (new, old) x { L[LW] | R0[RW] R1 R2 R3 }.
+// LDS map (dwords): 2 buffers x 2 row slots (new, old) x { L[LW] | R0[RW] R1 R2 R3 }, then [merge 2x256x4].
 // ---------------------------------------------------------------------------------------------
 template <int WIN, bool SUB>
-__device__ __forceinline__ void march_pass_lds(const uint32_t *row, int lofs, int rofs, int RW, uint32_t (&C)[KC][4])
+__device__ __forceinline__ void march_pass_lds(const uint32_t *lp, const uint32_t *rp, int RW, uint32_t (&C)[KC][4])
 {
     using G = Geo<WIN>;
     constexpr int NW = G::NW;
     constexpr int NR = NW + TMAX - 1;
     uint32_t Lw[NW];
 #pragma unroll
-    for (int j = 0; j < NW; ++j) Lw[j] = row[lofs + j];
+    for (int j = 0; j < NW; ++j) Lw[j] = lp[j];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         uint32_t Wr[NR];
-        const uint32_t *pr = row + rofs + c * RW;
+        const uint32_t *pr = rp + c * RW;
 #pragma unroll
         for (int i = 0; i < NR; ++i) Wr[i] = pr[i];
 #pragma unroll
@@ -461,8 +461,7 @@ __global__ void __launch_bounds__(256, (WIN <= 16 ? SADBM_WPE_LDS : 3)) sad_quad
 {
     using G = Geo<WIN>;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint4 *merge = reinterpret_cast<uint4 *>(smem);          // [2][256]
-    uint32_t *rows = smem + 2 * 256 * 4;                      // [2 buffers][2 slots][ROWW]
+    uint32_t *rows = smem;                                    // [2 buffers][2 slots][ROWW] at LDS offset 0
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -478,6 +477,7 @@ __global__ void __launch_bounds__(256, (WIN <= 16 ? SADBM_WPE_LDS : 3)) sad_quad
     uint8_t *out = p.out + (int64_t)blockIdx.z * p.out_stride;
     const int ocols = p.W - p.win;
     const int LW = p.LW, RW = p.RW, ROWW = LW + 4 * RW;
+    uint4 *merge = reinterpret_cast<uint4 *>(smem + 4 * ROWW);   // [2][256], 16-byte aligned (4*ROWW words)
     const int PADK = p.NCp * KC;                              // R segment starts at column xb - PADK
     const int xlim = p.W + PADR - 4;                          // last addressable dword of a padded row
 
@@ -540,18 +540,20 @@ __global__ void __launch_bounds__(256, (WIN <= 16 ? SADBM_WPE_LDS : 3)) sad_quad
         }
     };
 
+    const uint32_t *lp0 = rows + lofs, *rp0 = rows + rofs;
     const int nsteps = WIN - 1 + ny;
     stage(0);
     __syncthreads();
     for (int r = 0; r < nsteps; ++r) {
-        const uint32_t *buf = rows + (r & 1) * 2 * ROWW;
+        const int bo = (r & 1) * 2 * ROWW;
         if (active) {
 #if SADBM_FUSED_STEP
             if (r >= WIN) march_step_lds<WIN>(buf, buf + ROWW, lofs, rofs, RW, C);
             else          march_pass_lds<WIN, false>(buf, lofs, rofs, RW, C);
 #else
-            march_pass_lds<WIN, false>(buf, lofs, rofs, RW, C);
-            if (r >= WIN) march_pass_lds<WIN, true>(buf + ROWW, lofs, rofs, RW, C);
+            // per-thread LDS pointers: one VGPR base per image, small immediate offsets per word
+            march_pass_lds<WIN, false>(lp0 + bo, rp0 + bo, RW, C);
+            if (r >= WIN) march_pass_lds<WIN, true>(lp0 + bo + ROWW, rp0 + bo + ROWW, RW, C);
 #endif
         }
         if (r + 1 < nsteps) stage(r + 1);                     // other buffer: last read in step r-1

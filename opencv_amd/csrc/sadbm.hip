@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <new>
 
 #include "../../include/sadbm.h"
@@ -51,8 +52,8 @@ constexpr int PADR = 64;      // >= 4*NW + 8 for the widest window
 #ifndef SADBM_WPE
 #define SADBM_WPE 2
 #endif
-constexpr int KC = SADBM_KC;  // disparities per thread (multiple of 4)
-constexpr int TMAX = KC / 4;  // disparities per byte-alignment class
+constexpr int KCG = 16;       // disparities per thread of the L1-operand variant (sad_quad_kernel)
+
 constexpr int MAXWIN = 25;    // widest window with a dedicated instantiation
 constexpr uint32_t KEY_MAX = 0xFFFFFFFFu;
 
@@ -216,10 +217,12 @@ __device__ __forceinline__ void load_row_L(const uint8_t *row, int x0, uint32_t 
 //   HAS_OLD = true : C += H(new row) - H(old row)
 template <int WIN, bool HAS_OLD>
 __device__ __forceinline__ void march_step(const uint8_t *Lnew, const uint8_t *Rnew, const uint8_t *Lold,
-                                           const uint8_t *Rold, int x0, int k0, uint32_t (&C)[KC][4])
+                                           const uint8_t *Rold, int x0, int k0, uint32_t (&C)[KCG][4])
 {
     using G = Geo<WIN>;
     constexpr int NW = G::NW;
+    constexpr int KC = KCG, TMAX = KC / 4;
+    (void)KC;
     uint32_t Ln[NW], Lo[NW];
     load_row_L<WIN>(Lnew, x0, Ln);
     if constexpr (HAS_OLD) load_row_L<WIN>(Lold, x0, Lo);
@@ -260,7 +263,7 @@ __device__ __forceinline__ void march_step(const uint8_t *Lnew, const uint8_t *R
 // argmin over this thread's 16 disparities for the four columns of its quad.  `slow` (wave-uniform):
 // some lane sits at the left border (k > x0+a: the reference keeps cost 0 there, handled by the caller
 // through the j+1 candidate) or in the last chunk (k >= D); those slots are excluded.
-template <int WIN>
+template <int WIN, int KC>
 __device__ __forceinline__ void chunk_min(const uint32_t (&C)[KC][4], int k0, int kmaxrel0, int dlim, bool slow, uint32_t (&best)[4])
 {
     using G = Geo<WIN>;
@@ -290,6 +293,7 @@ template <int WIN>
 __global__ void __launch_bounds__(256, SADBM_WPE) sad_quad_kernel(Params p)
 {
     using G = Geo<WIN>;
+    constexpr int KC = KCG;
     __shared__ uint4 merge[2][256];
 
     const int tid = threadIdx.x;
@@ -338,7 +342,7 @@ __global__ void __launch_bounds__(256, SADBM_WPE) sad_quad_kernel(Params p)
         // ---- emit output row y ----
         const int y = yb + r - (WIN - 1);
         uint32_t best[4] = {KEY_MAX, KEY_MAX, KEY_MAX, KEY_MAX};
-        if (active) chunk_min<WIN>(C, k0, kmaxrel0, dlim, slow, best);
+        if (active) chunk_min<WIN, KC>(C, k0, kmaxrel0, dlim, slow, best);
         if (p.NCp > 1) {
             const int par = r & 1;
             if (c > 0) merge[par][tid] = make_uint4(best[0], best[1], best[2], best[3]);
@@ -386,11 +390,12 @@ __global__ void __launch_bounds__(256, SADBM_WPE) sad_quad_kernel(Params p)
 //     (consecutive lanes read consecutive dwords).
 // LDS map (dwords): 2 buffers x 2 row slots (new, old) x { L[LW] | R0[RW] R1 R2 R3 }, then [merge 2x256x4].
 // ---------------------------------------------------------------------------------------------
-template <int WIN, bool SUB>
+template <int WIN, int KC, bool SUB>
 __device__ __forceinline__ void march_pass_lds(const uint32_t *lp, const uint32_t *rp, int RW, uint32_t (&C)[KC][4])
 {
     using G = Geo<WIN>;
     constexpr int NW = G::NW;
+    constexpr int TMAX = KC / 4;
     constexpr int NR = NW + TMAX - 1;
     uint32_t Lw[NW];
 #pragma unroll
@@ -422,44 +427,12 @@ __device__ __forceinline__ void march_pass_lds(const uint32_t *lp, const uint32_
     }
 }
 
-// Steady-state step: C += H(new row) - H(old row) with the shared-word sums of both rows folded into
-// one difference per disparity:  C_a = ends_new(acc=C_a) - ends_old(acc = base_old - base_new).
-template <int WIN>
-__device__ __forceinline__ void march_step_lds(const uint32_t *rown, const uint32_t *rowo, int lofs, int rofs, int RW,
-                                               uint32_t (&C)[KC][4])
+// KC = disparities per thread: 16 (4 waves/SIMD) for D >= 128, 8 (5 waves/SIMD, more blocks) for D <= 64.
+template <int WIN, int KC>
+__global__ void __launch_bounds__(256, (KC == 16 ? (WIN <= 16 ? 4 : 3) : (WIN <= 16 ? 5 : 4))) sad_quad_lds_kernel(Params p)
 {
     using G = Geo<WIN>;
-    constexpr int NW = G::NW;
-    constexpr int NR = NW + TMAX - 1;
-    uint32_t Ln[NW], Lo[NW];
-#pragma unroll
-    for (int j = 0; j < NW; ++j) { Ln[j] = rown[lofs + j]; Lo[j] = rowo[lofs + j]; }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        uint32_t Wn[NR], Wo[NR];
-#pragma unroll
-        for (int i = 0; i < NR; ++i) { Wn[i] = rown[rofs + c * RW + i]; Wo[i] = rowo[rofs + c * RW + i]; }
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-            const int kk = c + 4 * t;
-            const uint32_t *Rn = &Wn[TMAX - 1 - t];
-            const uint32_t *Ro = &Wo[TMAX - 1 - t];
-            uint32_t bn0, bn1, bo0, bo1;
-            row_bases<WIN>(Ln, Rn, bn0, bn1);
-            row_bases<WIN>(Lo, Ro, bo0, bo1);
-            const uint32_t d0 = bo0 - bn0, d1 = bo1 - bn1;
-            C[kk][0] = row_ends<WIN, 0>(Ln, Rn, C[kk][0]) - row_ends<WIN, 0>(Lo, Ro, base_sel<WIN, 0>(d0, d1));
-            C[kk][1] = row_ends<WIN, 1>(Ln, Rn, C[kk][1]) - row_ends<WIN, 1>(Lo, Ro, base_sel<WIN, 1>(d0, d1));
-            C[kk][2] = row_ends<WIN, 2>(Ln, Rn, C[kk][2]) - row_ends<WIN, 2>(Lo, Ro, base_sel<WIN, 2>(d0, d1));
-            C[kk][3] = row_ends<WIN, 3>(Ln, Rn, C[kk][3]) - row_ends<WIN, 3>(Lo, Ro, base_sel<WIN, 3>(d0, d1));
-        }
-    }
-}
-
-template <int WIN>
-__global__ void __launch_bounds__(256, (WIN <= 16 ? SADBM_WPE_LDS : 3)) sad_quad_lds_kernel(Params p)
-{
-    using G = Geo<WIN>;
+    constexpr int TMAX = KC / 4;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *rows = smem;                                    // [2 buffers][2 slots][ROWW] at LDS offset 0
 
@@ -547,21 +520,16 @@ __global__ void __launch_bounds__(256, (WIN <= 16 ? SADBM_WPE_LDS : 3)) sad_quad
     for (int r = 0; r < nsteps; ++r) {
         const int bo = (r & 1) * 2 * ROWW;
         if (active) {
-#if SADBM_FUSED_STEP
-            if (r >= WIN) march_step_lds<WIN>(buf, buf + ROWW, lofs, rofs, RW, C);
-            else          march_pass_lds<WIN, false>(buf, lofs, rofs, RW, C);
-#else
             // per-thread LDS pointers: one VGPR base per image, small immediate offsets per word
-            march_pass_lds<WIN, false>(lp0 + bo, rp0 + bo, RW, C);
-            if (r >= WIN) march_pass_lds<WIN, true>(lp0 + bo + ROWW, rp0 + bo + ROWW, RW, C);
-#endif
+            march_pass_lds<WIN, KC, false>(lp0 + bo, rp0 + bo, RW, C);
+            if (r >= WIN) march_pass_lds<WIN, KC, true>(lp0 + bo + ROWW, rp0 + bo + ROWW, RW, C);
         }
         if (r + 1 < nsteps) stage(r + 1);                     // other buffer: last read in step r-1
         const bool emit = r >= WIN - 1;                       // block-uniform
         uint32_t best[4] = {KEY_MAX, KEY_MAX, KEY_MAX, KEY_MAX};
         const int par = r & 1;
         if (emit) {
-            if (active) chunk_min<WIN>(C, k0, kmaxrel0, dlim, slow, best);
+            if (active) chunk_min<WIN, KC>(C, k0, kmaxrel0, dlim, slow, best);
             if (c > 0) merge[par * 256 + tid] = make_uint4(best[0], best[1], best[2], best[3]);
         }
         __syncthreads();
@@ -637,10 +605,11 @@ static quad_kernel_t pick_quad_kernel(int win, Seq<I...>)
     return table[win - 1];
 }
 template <int... I>
-static quad_kernel_t pick_quad_lds_kernel(int win, Seq<I...>)
+static quad_kernel_t pick_quad_lds_kernel(int win, int kc, Seq<I...>)
 {
-    static const quad_kernel_t table[] = { sad_quad_lds_kernel<I + 1>... };
-    return table[win - 1];
+    static const quad_kernel_t t16[] = { sad_quad_lds_kernel<I + 1, 16>... };
+    static const quad_kernel_t t8[] = { sad_quad_lds_kernel<I + 1, 8>... };
+    return kc == 16 ? t16[win - 1] : t8[win - 1];
 }
 
 }  // namespace
@@ -742,6 +711,11 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         hipLaunchKernelGGL(sad_generic_kernel, g, dim3(256), 0, st, p);
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_generic_kernel");
     } else {
+        const bool use_global = (flags & SADBM_KERNEL_GLOBAL) != 0;
+        // disparities per thread: 16 keeps the per-row L work amortised for wide searches; 8 gives twice
+        // the blocks and 5 waves/SIMD for D <= 64 (measured: cfg2 0.32 -> 0.25 ms, cfg3 0.78 vs 0.85 ms)
+        int KC = use_global ? KCG : (D <= 64 ? 8 : 16);
+        if (!use_global) { const char *e = getenv("SADBM_KC"); if (e && (atoi(e) == 8 || atoi(e) == 16)) KC = atoi(e); }
         const int NC = (D + KC - 1) / KC;                     // <= 256/KC
         p.NCp = pow2ceil(NC);
         const int quads = (cols + 3) / 4;
@@ -754,7 +728,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         while (TY > 16 && (long)bx * ((nvalid + TY - 1) / TY) * n_pairs < 1024) TY >>= 1;
         p.TY = TY;
         dim3 g(bx, (nvalid + TY - 1) / TY, n_pairs);
-        if (flags & SADBM_KERNEL_GLOBAL) {
+        if (use_global) {
             quad_kernel_t k = pick_quad_kernel(win, MakeSeq<MAXWIN>::type());
             hipLaunchKernelGGL(k, g, dim3(p.NQ * p.NCp), 0, st, p);
             snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_quad_kernel<%d>", win);
@@ -763,9 +737,9 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
             p.LW = p.NQ + NW;
             p.RW = p.NQ + NW + p.NCp * KC / 4 + 1;
             const size_t lds = (size_t)(2 * 256 * 4 + 4 * (p.LW + 4 * p.RW)) * 4;
-            quad_kernel_t k = pick_quad_lds_kernel(win, MakeSeq<MAXWIN>::type());
+            quad_kernel_t k = pick_quad_lds_kernel(win, KC, MakeSeq<MAXWIN>::type());
             hipLaunchKernelGGL(k, g, dim3(p.NQ * p.NCp), lds, st, p);
-            snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_quad_lds_kernel<%d>", win);
+            snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_quad_lds_kernel<%d,%d>", win, KC);
         }
     }
     HIPCHK(hipGetLastError());

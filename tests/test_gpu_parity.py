@@ -57,6 +57,19 @@ def test_sweep_matches_oracle(win, D):
         assert np.array_equal(got, exp), ("global", win, D, binary, np.argwhere(got != exp)[:5])
 
 
+@pytest.mark.parametrize("kc", ["8", "16"])
+@pytest.mark.parametrize("win,D", [(7, 30), (9, 64), (15, 128), (21, 256), (16, 200), (3, 17), (1, 1)])
+def test_both_disparity_chunkings(kc, win, D, monkeypatch):
+    """The matcher is instantiated for 8 and 16 disparities per thread (chosen by D); force each."""
+    monkeypatch.setenv("SADBM_KC", kc)
+    L, R = noise_pair(win + D, 70, 333, shift=9)
+    exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
+    ctx = oa.Context(0)
+    got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC, ctx=ctx).cpu().numpy()
+    assert ctx.last_kernel() == "sad_quad_lds_kernel<%d,%s>" % (win, kc)
+    assert np.array_equal(got, exp)
+
+
 @pytest.mark.parametrize("shape", [(9, 300), (300, 9), (40, 17), (8, 8), (7, 50), (50, 7), (1, 1), (33, 129)])
 def test_small_and_degenerate_shapes(shape):
     H, W = shape

@@ -468,50 +468,49 @@ __global__ void __launch_bounds__(256, (KC == 16 ? (WIN <= 16 ? 4 : 3) : (WIN <=
 #pragma unroll
         for (int a = 0; a < 4; ++a) C[kk][a] = G::HI16 ? (uint32_t)(k0 + kk) : 0u;
 
-    // Staging descriptors, computed once: element e of this thread is LDS word tid + e*nthr of a row slot
-    // and comes from byte offset goff[e] of the row (relative to the L plane; R elements carry R - L).
-    // G_NONE marks a word beyond the padded row (kept zero).
-    constexpr int STG = 6;                                    // >= ceil(ROWW / blockDim) for every geometry
-    constexpr int G_NONE = INT32_MIN, G_RBIT = 1 << 24;       // offsets lie in (-2^20, 2^20)
-    int goff[STG];                                            // (byte offset + 2^20) | G_RBIT for R elements
-#pragma unroll
-    for (int e = 0; e < STG; ++e) {
-        const int w = tid + e * nthr;
-        int g = G_NONE;
-        if (w < LW) {
-            const int off = xb + 4 * w;
-            if (off <= xlim) g = off + (1 << 20);
-        } else if (w < ROWW) {
-            const int cc = (w - LW) / RW;
-            const int i = (w - LW) - cc * RW;
-            const int off = xb - PADK + 4 * i - cc;
-            if (off <= xlim) g = (off + (1 << 20)) | G_RBIT;
-        }
-        goff[e] = g;
-    }
+    // Staging roles (no per-element index arithmetic): thread group g (64 threads, or the whole block when
+    // it is smaller) copies shifted R copy g, g+ng, ...; every thread helps with the L segment.
+    const int SG = nthr < 64 ? nthr : 64;
+    const int sg = tid / SG, sl = tid - sg * SG, ng = nthr / SG;
     // stage the rows of marching step r into buffer (r & 1): slot 0 = new row yb+r, slot 1 = old row yb+r-WIN
     auto stage = [&](int r) {
         uint32_t *dst = rows + (r & 1) * 2 * ROWW;
-        const int64_t rn = (int64_t)(yb + r) * p.pitch - (1 << 20);
-        const int64_t ro = (int64_t)(yb + r - WIN) * p.pitch - (1 << 20);
+        const uint8_t *Ln = L + (int64_t)(yb + r) * p.pitch, *Rn = R + (int64_t)(yb + r) * p.pitch;
+        const int64_t back = (int64_t)WIN * p.pitch;          // old row = new row - WIN rows
         const bool has_old = r >= WIN;
-#pragma unroll
-        for (int e = 0; e < STG; ++e) {
-            const int w = tid + e * nthr;
-            if (w < ROWW) {
-                const int g = goff[e];
+        for (int i = tid; i < LW; i += nthr) {
+            const int off = xb + 4 * i;
+            uint32_t vn = 0, vo = 0;
+            if (off <= xlim) {
+                vn = *(const uint32_t *)(Ln + off);
+                if (has_old) vo = *(const uint32_t *)(Ln + off - back);
+            }
+            dst[i] = vn;
+            if (has_old) dst[ROWW + i] = vo;
+        }
+        for (int cc = sg; cc < 4; cc += ng) {
+            uint32_t *d = dst + LW + cc * RW;
+            for (int i = sl; i < RW; i += SG) {
+                const int off = xb - PADK + 4 * i - cc;
                 uint32_t vn = 0, vo = 0;
-                if (g != G_NONE) {
-                    const uint8_t *base = (g & G_RBIT) ? R : L;
-                    const int o = g & (G_RBIT - 1);
-                    vn = *(const u32u *)(base + rn + o);
-                    if (has_old) vo = *(const u32u *)(base + ro + o);
+                if (off <= xlim) {
+                    vn = *(const u32u *)(Rn + off);
+                    if (has_old) vo = *(const u32u *)(Rn + off - back);
                 }
-                dst[w] = vn;
-                if (has_old) dst[ROWW + w] = vo;
+                d[i] = vn;
+                if (has_old) d[ROWW + i] = vo;
             }
         }
     };
+
+    // Common geometry (256 threads, RW <= 128): every thread owns <= 1 L word and <= 2 R words of a row, so
+    // the next step's rows are fetched into registers BEFORE the compute of this step and written to the
+    // other LDS buffer after it -- the global-load latency hides behind ~600 VALU instructions.
+    const bool fastgeo = (nthr == 256) && (LW <= 256) && (RW <= 128);
+    const int pf_lo = xb + 4 * tid;                           // L word of this thread
+    const int pf_r0 = xb - PADK + 4 * sl - sg, pf_r1 = pf_r0 + 4 * 64;   // R words sl and sl+64 of copy sg
+    const bool pf_lv = fastgeo && tid < LW && pf_lo <= xlim;
+    const bool pf_r0v = fastgeo && sl < RW && pf_r0 <= xlim, pf_r1v = fastgeo && sl + 64 < RW && pf_r1 <= xlim;
 
     const uint32_t *lp0 = rows + lofs, *rp0 = rows + rofs;
     const int nsteps = WIN - 1 + ny;
@@ -519,12 +518,32 @@ __global__ void __launch_bounds__(256, (KC == 16 ? (WIN <= 16 ? 4 : 3) : (WIN <=
     __syncthreads();
     for (int r = 0; r < nsteps; ++r) {
         const int bo = (r & 1) * 2 * ROWW;
+        const bool more = r + 1 < nsteps;
+        const bool nold = r + 1 >= WIN;                       // step r+1 has a leaving row
+        uint32_t pl[2] = {0, 0}, pr0[2] = {0, 0}, pr1[2] = {0, 0};
+        if (fastgeo && more) {
+            const uint8_t *Ln = L + (int64_t)(yb + r + 1) * p.pitch, *Rn = R + (int64_t)(yb + r + 1) * p.pitch;
+            const int64_t back = (int64_t)WIN * p.pitch;
+            if (pf_lv) { pl[0] = *(const uint32_t *)(Ln + pf_lo); if (nold) pl[1] = *(const uint32_t *)(Ln + pf_lo - back); }
+            if (pf_r0v) { pr0[0] = *(const u32u *)(Rn + pf_r0); if (nold) pr0[1] = *(const u32u *)(Rn + pf_r0 - back); }
+            if (pf_r1v) { pr1[0] = *(const u32u *)(Rn + pf_r1); if (nold) pr1[1] = *(const u32u *)(Rn + pf_r1 - back); }
+        }
         if (active) {
             // per-thread LDS pointers: one VGPR base per image, small immediate offsets per word
             march_pass_lds<WIN, KC, false>(lp0 + bo, rp0 + bo, RW, C);
             if (r >= WIN) march_pass_lds<WIN, KC, true>(lp0 + bo + ROWW, rp0 + bo + ROWW, RW, C);
         }
-        if (r + 1 < nsteps) stage(r + 1);                     // other buffer: last read in step r-1
+        if (more) {                                           // other buffer: last read in step r-1
+            if (fastgeo) {
+                uint32_t *dst = rows + ((r + 1) & 1) * 2 * ROWW;
+                if (tid < LW) { dst[tid] = pl[0]; if (nold) dst[ROWW + tid] = pl[1]; }
+                uint32_t *d = dst + LW + sg * RW;
+                if (sl < RW) { d[sl] = pr0[0]; if (nold) d[ROWW + sl] = pr0[1]; }
+                if (sl + 64 < RW) { d[sl + 64] = pr1[0]; if (nold) d[ROWW + sl + 64] = pr1[1]; }
+            } else {
+                stage(r + 1);
+            }
+        }
         const bool emit = r >= WIN - 1;                       // block-uniform
         uint32_t best[4] = {KEY_MAX, KEY_MAX, KEY_MAX, KEY_MAX};
         const int par = r & 1;

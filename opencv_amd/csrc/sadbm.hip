@@ -46,8 +46,11 @@ constexpr int PADR = 64;      // >= 4*NW + 8 for the widest window
 #ifndef SADBM_MERGE_ENDS
 #define SADBM_MERGE_ENDS 1
 #endif
+#ifndef SADBM_MINBLOCKS
+#define SADBM_MINBLOCKS 2000
+#endif
 #ifndef SADBM_TYMAX
-#define SADBM_TYMAX 64
+#define SADBM_TYMAX 128
 #endif
 #ifndef SADBM_WPE
 #define SADBM_WPE 2
@@ -744,7 +747,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         // rows per block: long bands amortise the win-1 warm-up rows; shorten them until the grid
         // has a few blocks per CU.
         int TY = SADBM_TYMAX;
-        while (TY > 16 && (long)bx * ((nvalid + TY - 1) / TY) * n_pairs < 1024) TY >>= 1;
+        while (TY > 16 && (long)bx * ((nvalid + TY - 1) / TY) * n_pairs < SADBM_MINBLOCKS) TY >>= 1;
         p.TY = TY;
         dim3 g(bx, (nvalid + TY - 1) / TY, n_pairs);
         if (use_global) {

@@ -203,3 +203,37 @@ def test_cfg4_band_geometry_matches_oracle():
         assert np.array_equal(got, exp), b
         if b == 7:
             assert nvalid == 540 - 21 and not got[nvalid:].any()
+
+
+def test_full_size_4k_config3_properties_and_band_of_oracle():
+    """BASELINE config 3 at full size (3840x2160, 15x15, D=128).  Whole-frame checks are size-independent
+    properties; a 200-row band is compared bit-for-bit with the sliding-sum oracle."""
+    W, H, win, D = 3840, 2160, 15, 128
+    L, R = oracle.rds(3, W, H, 16, 96, 0)
+    got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC).cpu().numpy()
+    # zero frame (SAD.cpp:31,34,36)
+    assert not got[H - win:, :].any() and not got[:, W - win:].any()
+    # left border ramp (SAD.cpp:40,44): loc = j+1 for j < d_bg, then the planted disparity is found exactly
+    assert (got[10, :16] == np.arange(1, 17)).all()
+    assert (got[100, 200:900] == 16).all() and (got[1000, 1200:2700] == 96).all()
+    # the planted disparity dominates: background rows are d_bg, foreground box is d_fg
+    assert (got[: H // 4 - win, 16: W - win - 16] == 16).mean() > 0.999
+    # idempotence / determinism
+    again = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC).cpu().numpy()
+    assert np.array_equal(got, again)
+    # band 500..700 against the oracle (needs input rows 500..715)
+    r0, n = 500, 200
+    exp = oracle.box(L[r0: r0 + n + win], R[r0: r0 + n + win], win, D, oracle.RAW_LOC)[:n]
+    assert np.array_equal(got[r0: r0 + n], exp)
+    # encode relation (SAD.cpp:57): default output == (loc*16)&255
+    enc = oa.compute_device(dev(L), dev(R), win, D).cpu().numpy()
+    assert np.array_equal(enc, (got.astype(np.int32) * 16 & 255).astype(np.uint8))
+
+
+def test_config5_kitti_batch_against_oracle():
+    """BASELINE config 5 geometry: 1242x375 pairs, D=128, 7x7; a batch of 6 distinct pairs."""
+    W, H, win, D = 1242, 375, 7, 128
+    pairs = [oracle.rds(1000 + n, W, H, 5 + n % 16, 60 + n % 64, 0) for n in range(6)]
+    out = oa.compute_batch_device(dev(np.stack([p[0] for p in pairs])), dev(np.stack([p[1] for p in pairs])), win, D).cpu().numpy()
+    for n, (L, R) in enumerate(pairs):
+        assert np.array_equal(out[n], oracle.box(L, R, win, D)), n

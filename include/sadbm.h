@@ -34,6 +34,8 @@ extern "C" {
 #define SADBM_RAW_LOC        1u   /* write loc (0..max_disp-1) instead of (loc*16)&255; needs max_disp<=256 */
 #define SADBM_FORCE_GENERIC  2u   /* use the brute-force HIP kernel (any win); for cross-checks */
 #define SADBM_KERNEL_GLOBAL  4u   /* use the matcher variant that reads operands through L1 instead of LDS (A/B) */
+#define SADBM_KERNEL_STRIP   8u   /* force the strip matcher (16 columns x 4 disparities per thread; 4 <= win <= 25) */
+#define SADBM_KERNEL_QUAD   16u   /* force the quad matcher (4 columns x 8/16 disparities per thread) */
 
 /* error codes */
 #define SADBM_OK        0

@@ -616,7 +616,10 @@ __global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
     out[x] = (p.flags & SADBM_RAW_LOC) ? (uint8_t)loc : (uint8_t)((loc * 16u) & 0xFFu);
 }
 
+#include "sad_strip.inc"
+
 typedef void (*quad_kernel_t)(Params);
+typedef void (*strip_kernel_t)(strip::SParams);
 template <int... I> struct Seq {};
 template <int N, int... I> struct MakeSeq : MakeSeq<N - 1, N - 1, I...> {};
 template <int... I> struct MakeSeq<0, I...> { typedef Seq<I...> type; };
@@ -632,6 +635,22 @@ static quad_kernel_t pick_quad_lds_kernel(int win, int kc, Seq<I...>)
     static const quad_kernel_t t16[] = { sad_quad_lds_kernel<I + 1, 16>... };
     static const quad_kernel_t t8[] = { sad_quad_lds_kernel<I + 1, 8>... };
     return kc == 16 ? t16[win - 1] : t8[win - 1];
+}
+
+#ifndef SADBM_STRIP_WINS
+#define SADBM_STRIP_WINS 25
+#endif
+template <int WIN>
+static strip_kernel_t strip_entry()
+{
+    if constexpr (WIN >= 4 && WIN <= SADBM_STRIP_WINS && strip::SG<WIN>::ok) return strip::sad_strip_kernel<WIN>;
+    else return nullptr;
+}
+template <int... I>
+static strip_kernel_t pick_strip_kernel(int win, Seq<I...>)
+{
+    static const strip_kernel_t table[] = { strip_entry<I + 1>()... };
+    return table[win - 1];
 }
 
 }  // namespace
@@ -685,6 +704,16 @@ int check_params(int rows, int cols, int channels, int win, int max_disp, uint32
 
 int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+#ifndef SADBM_STRIP_MINBLOCKS
+#define SADBM_STRIP_MINBLOCKS 500
+#endif
+// default matcher choice (measured): strip matcher off until it wins
+bool strip_is_default(int win, int D, int cols)
+{
+    (void)win; (void)D; (void)cols;
+    return false;
+}
+
 // The whole device pipeline for n_pairs frames (or one band).  Input rows available: rows_in; output
 // rows written: rows_out; output rows [0,nvalid) are computed, the rest zero-filled.
 int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_t *dR, int64_t pitchR,
@@ -708,25 +737,60 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     const int need_rows = nvalid + win - 1;                   // <= rows_in (checked by callers)
     const int pitch = (PADL + cols + PADR + 127) & ~127;
     const size_t plane_bytes = (size_t)pitch * (size_t)need_rows;
-    int rc = grow(&ctx->planes, &ctx->planes_cap, 2 * plane_bytes * (size_t)n_pairs);
+    // scratch layout: [pair][L plane | R plane], + slack: the strip matcher stages whole 256-column blocks
+    // and may read a few hundred bytes past the last row (values only reach columns >= cols-win, which are 0)
+    int rc = grow(&ctx->planes, &ctx->planes_cap, 2 * plane_bytes * (size_t)n_pairs + 4096);
     if (rc) return rc;
-    uint8_t *pL = ctx->planes, *pR = ctx->planes + plane_bytes * (size_t)n_pairs;
+    uint8_t *pL = ctx->planes, *pR = ctx->planes + plane_bytes;
 
     const bool prof = ctx->prof_on && ctx->ev_n < ctx->ev_cap;
     hipEvent_t *ev = prof ? ctx->ev + 3 * ctx->ev_n : nullptr;
     if (prof) HIPCHK(hipEventRecord(ev[0], st));
     dim3 pg((pitch / 4 + 255) / 256, need_rows, n_pairs);
-    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dL, pitchL, pair_stride_in, channels, need_rows, cols, pL, pitch, (int64_t)plane_bytes);
-    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dR, pitchR, pair_stride_in, channels, need_rows, cols, pR, pitch, (int64_t)plane_bytes);
+    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dL, pitchL, pair_stride_in, channels, need_rows, cols, pL, pitch, (int64_t)(2 * plane_bytes));
+    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dR, pitchR, pair_stride_in, channels, need_rows, cols, pR, pitch, (int64_t)(2 * plane_bytes));
     HIPCHK(hipGetLastError());
 
     Params p;
-    p.L = pL + PADL; p.R = pR + PADL; p.plane_stride = (int64_t)plane_bytes; p.pitch = pitch;
+    p.L = pL + PADL; p.R = pR + PADL; p.plane_stride = (int64_t)(2 * plane_bytes); p.pitch = pitch;
     p.W = cols; p.nvalid = nvalid; p.win = win; p.D = D;
     p.out = dOut; p.out_pitch = out_pitch; p.out_stride = pair_stride_out; p.flags = flags;
     p.dword_store = ((((uintptr_t)dOut) | (uintptr_t)out_pitch | (uintptr_t)pair_stride_out) & 3) == 0;
     p.NQ = 0; p.NCp = 0; p.TY = 0; p.LW = 0; p.RW = 0;
     if (prof) HIPCHK(hipEventRecord(ev[1], st));
+
+    // matcher choice: SADBM_KERNEL_STRIP / SADBM_KERNEL_QUAD force one; env SADBM_MATCHER=strip|quad overrides the default
+    bool use_strip = false;
+    strip_kernel_t sk = (win <= MAXWIN) ? pick_strip_kernel(win, MakeSeq<MAXWIN>::type()) : nullptr;
+    if (sk && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL | SADBM_KERNEL_QUAD))) {
+        use_strip = (flags & SADBM_KERNEL_STRIP) != 0 || strip_is_default(win, D, cols);
+        const char *e = getenv("SADBM_MATCHER");
+        if (e && !(flags & SADBM_KERNEL_STRIP)) use_strip = strcmp(e, "strip") == 0 ? true : (strcmp(e, "quad") == 0 ? false : use_strip);
+    }
+    if (use_strip) {
+        strip::SParams q;
+        const int Dp = (D + 63) & ~63;
+        q.NG = Dp / 16;
+        q.Lrow0 = pL; q.pair_stride = (int64_t)(2 * plane_bytes); q.lr_delta = (uint32_t)plane_bytes;
+        q.pitch = pitch; q.W = cols; q.nvalid = nvalid; q.win = win; q.D = D;
+        q.out = dOut; q.out_pitch = out_pitch; q.out_stride = pair_stride_out; q.flags = flags; q.dword_store = p.dword_store;
+        const int bx = (cols + strip::XBW - 1) / strip::XBW;
+        int TY = SADBM_TYMAX;
+        while (TY > 32 && (long)bx * ((nvalid + TY - 1) / TY) * n_pairs < SADBM_STRIP_MINBLOCKS) TY >>= 1;
+        { const char *e = getenv("SADBM_STRIP_TY"); if (e && atoi(e) >= 1) TY = atoi(e); }
+        q.TY = TY;
+        const int NSL = strip::NS + q.NG;
+        const int ROWW = 4 * (strip::NS + 2) + 16 * strip::NS + 16 * (NSL + 3) + 64 * NSL;
+        const int NUP = ((20 * NSL + 12 + 5 * strip::NS + 2) + 63) & ~63;
+        const size_t lds = (size_t)(4 * ROWW + 4 * NUP + 2 * 4 * 64) * 4;
+        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        dim3 g(bx, (nvalid + TY - 1) / TY, n_pairs);
+        hipLaunchKernelGGL(sk, g, dim3(64 * q.NG), lds, st, q);
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_strip_kernel<%d>", win);
+        HIPCHK(hipGetLastError());
+        if (prof) { HIPCHK(hipEventRecord(ev[2], st)); ctx->ev_n++; }
+        return SADBM_OK;
+    }
 
     if (win > MAXWIN || (flags & SADBM_FORCE_GENERIC)) {
         dim3 g((cols + 255) / 256, nvalid, n_pairs);

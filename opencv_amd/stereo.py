@@ -15,6 +15,8 @@ import numpy as np
 RAW_LOC = 1
 FORCE_GENERIC = 2
 KERNEL_GLOBAL = 4
+KERNEL_STRIP = 8
+KERNEL_QUAD = 16
 DEFAULT_WIN_SIZE = 7     # SAD.cpp:9
 DEFAULT_DSR = 30         # SAD.cpp:11
 

@@ -640,17 +640,20 @@ static quad_kernel_t pick_quad_lds_kernel(int win, int kc, Seq<I...>)
 #ifndef SADBM_STRIP_WINS
 #define SADBM_STRIP_WINS 25
 #endif
-template <int WIN>
+template <int WIN, int NSLM>
 static strip_kernel_t strip_entry()
 {
-    if constexpr (WIN >= 4 && WIN <= SADBM_STRIP_WINS && strip::SG<WIN>::ok) return strip::sad_strip_kernel<WIN>;
+    if constexpr (WIN >= 4 && WIN <= SADBM_STRIP_WINS && strip::SG<WIN>::ok) return strip::sad_strip_kernel<WIN, NSLM>;
     else return nullptr;
 }
+// nslm = NS + (4, 8 or 16 disparity groups): 64, 128 or 256 disparities per block
 template <int... I>
-static strip_kernel_t pick_strip_kernel(int win, Seq<I...>)
+static strip_kernel_t pick_strip_kernel(int win, int nslm, Seq<I...>)
 {
-    static const strip_kernel_t table[] = { strip_entry<I + 1>()... };
-    return table[win - 1];
+    static const strip_kernel_t t20[] = { strip_entry<I + 1, strip::NS + 4>()... };
+    static const strip_kernel_t t24[] = { strip_entry<I + 1, strip::NS + 8>()... };
+    static const strip_kernel_t t32[] = { strip_entry<I + 1, strip::NS + 16>()... };
+    return nslm == strip::NS + 4 ? t20[win - 1] : nslm == strip::NS + 8 ? t24[win - 1] : t32[win - 1];
 }
 
 }  // namespace
@@ -761,7 +764,8 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
 
     // matcher choice: SADBM_KERNEL_STRIP / SADBM_KERNEL_QUAD force one; env SADBM_MATCHER=strip|quad overrides the default
     bool use_strip = false;
-    strip_kernel_t sk = (win <= MAXWIN) ? pick_strip_kernel(win, MakeSeq<MAXWIN>::type()) : nullptr;
+    const int strip_ng = D <= 64 ? 4 : D <= 128 ? 8 : 16;    // disparity groups of 16 per block (multiple of 4)
+    strip_kernel_t sk = (win <= MAXWIN) ? pick_strip_kernel(win, strip::NS + strip_ng, MakeSeq<MAXWIN>::type()) : nullptr;
     if (sk && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL | SADBM_KERNEL_QUAD))) {
         use_strip = (flags & SADBM_KERNEL_STRIP) != 0 || strip_is_default(win, D, cols);
         const char *e = getenv("SADBM_MATCHER");
@@ -769,8 +773,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     }
     if (use_strip) {
         strip::SParams q;
-        const int Dp = (D + 63) & ~63;
-        q.NG = Dp / 16;
+        q.NG = strip_ng;
         q.Lrow0 = pL; q.pair_stride = (int64_t)(2 * plane_bytes); q.lr_delta = (uint32_t)plane_bytes;
         q.pitch = pitch; q.W = cols; q.nvalid = nvalid; q.win = win; q.D = D;
         q.out = dOut; q.out_pitch = out_pitch; q.out_stride = pair_stride_out; q.flags = flags; q.dword_store = p.dword_store;
@@ -780,7 +783,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         { const char *e = getenv("SADBM_STRIP_TY"); if (e && atoi(e) >= 1) TY = atoi(e); }
         q.TY = TY;
         const int NSL = strip::NS + q.NG;
-        const int ROWW = 4 * (strip::NS + 2) + 16 * strip::NS + 16 * (NSL + 3) + 64 * NSL;
+        const int ROWW = 4 * (strip::NS + 2) + 16 * strip::NS + 16 * (NSL + 3) + 64 * NSL;   // strip::Lay<NSL>::ROWW
         const int NUP = ((20 * NSL + 12 + 5 * strip::NS + 2) + 63) & ~63;
         const size_t lds = (size_t)(4 * ROWW + 4 * NUP + 2 * 4 * 64) * 4;
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

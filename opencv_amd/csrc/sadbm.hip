@@ -640,6 +640,26 @@ static quad_kernel_t pick_quad_lds_kernel(int win, int kc, Seq<I...>)
 #ifndef SADBM_STRIP_WINS
 #define SADBM_STRIP_WINS 25
 #endif
+template <int WIN>
+static int strip_passes_one(int nsl)
+{
+    if constexpr (WIN >= 4 && WIN <= SADBM_STRIP_WINS && strip::SG<WIN>::ok) {
+        using SP = strip::StagePlan<WIN>;
+        return ((SP::n_single(nsl) + 63) >> 6) + ((SP::n_double(nsl) + 63) >> 6);
+    } else {
+        (void)nsl;
+        return 0;
+    }
+}
+template <int... I>
+static int strip_passes_table(int win, int nsl, Seq<I...>)
+{
+    typedef int (*fn_t)(int);
+    static const fn_t table[] = { strip_passes_one<I + 1>... };
+    return table[win - 1](nsl);
+}
+static int strip_passes_per_row(int win, int nsl) { return strip_passes_table(win, nsl, MakeSeq<MAXWIN>::type()); }
+
 template <int WIN, int NSLM>
 static strip_kernel_t strip_entry()
 {
@@ -784,8 +804,8 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         q.TY = TY;
         const int NSL = strip::NS + q.NG;
         const int ROWW = 4 * (strip::NS + 2) + 16 * strip::NS + 16 * (NSL + 3) + 64 * NSL;   // strip::Lay<NSL>::ROWW
-        const int NUP = ((20 * NSL + 12 + 5 * strip::NS + 2) + 63) & ~63;
-        const size_t lds = (size_t)(4 * ROWW + 4 * NUP + 2 * 4 * 64) * 4;
+        const int PR = strip_passes_per_row(win, NSL);
+        const size_t lds = (size_t)(4 * ROWW + 4 * 64 * PR + 2 * 4 * 64) * 4;
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         dim3 g(bx, (nvalid + TY - 1) / TY, n_pairs);
         hipLaunchKernelGGL(sk, g, dim3(64 * q.NG), lds, st, q);

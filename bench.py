@@ -161,7 +161,7 @@ def main():
     valu_ops = 7.0 * W * H * D * pairs * frac_rows
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        with open(os.path.join(ROOT, "bench_traffic.json")) as f:
             tj = json.load(f)
         ent = tj.get("%s|%s|pairs=%d" % (args.workload, ctx.last_kernel(), pairs))
         if ent and not bands:

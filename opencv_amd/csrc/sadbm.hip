@@ -102,6 +102,16 @@ __global__ void __launch_bounds__(256) prep_plane_kernel(const uint8_t *__restri
     *(uint32_t *)(dst + (int64_t)blockIdx.z * dst_stride + (int64_t)y * pitch + wi * 4) = v;
 }
 
+// The zero frame of SAD.cpp:31,34: output rows [row0, row0+nrows) of every pair (any pitch / alignment).
+__global__ void __launch_bounds__(256) zero_rows_kernel(uint8_t *out, int64_t out_pitch, int64_t out_stride, int row0, int nrows, int cols)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x >= cols) return;
+    uint8_t *o = out + (int64_t)blockIdx.z * out_stride + (int64_t)(row0 + blockIdx.y) * out_pitch + x;
+    if (x + 3 < cols && (((uintptr_t)o) & 3) == 0) { *(uint32_t *)o = 0; return; }
+    for (int b = 0; b < 4 && x + b < cols; ++b) o[b] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // 2. the matcher
 // ---------------------------------------------------------------------------------------------
@@ -730,11 +740,38 @@ int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 #ifndef SADBM_STRIP_MINBLOCKS
 #define SADBM_STRIP_MINBLOCKS 500
 #endif
-// default matcher choice (measured): strip matcher off until it wins
-bool strip_is_default(int win, int D, int cols)
+int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG)
 {
-    (void)win; (void)D; (void)cols;
-    return false;
+    const char *e = getenv("SADBM_STRIP_TY");
+    if (e && atoi(e) >= 1) return atoi(e);
+    const long cus = 256, per_cu = NG <= 8 ? 2 : 1, slots = cus * per_cu;
+    const long cols = (long)bx * n_pairs;
+    double best = 1e30; int best_ty = nvalid < 128 ? (nvalid > 0 ? nvalid : 1) : 128;
+    for (long m = 1; m <= 24; ++m) {
+        long nby = slots * m / cols;
+        if (nby < 1) continue;
+        if (nby > nvalid) nby = nvalid;
+        const int ty = (int)((nvalid + nby - 1) / nby);
+        if (ty > 512) continue;
+        const long rnby = (nvalid + ty - 1) / ty, blocks = cols * rnby;
+        const long full = blocks / slots, rem = blocks - full * slots;
+        double rounds = (double)full;
+        if (rem > 0) rounds += (per_cu == 2 && rem <= cus) ? 0.65 : 1.0;
+        const double cost = (rounds + 0.4) * (ty + win - 1);   // +0.4: finer grids balance better (measured, tools/dbg/ty.sh)
+        if (cost < best) { best = cost; best_ty = ty; }
+    }
+    return best_ty;
+}
+
+// Default matcher choice, from tools/sweep.py and bench.py on MI355X (profiles/r01e_*): the strip matcher needs
+// >= 65 disparities to amortise its staged R words; it wins for windows the quad matcher handles badly (win = 1 mod 4:
+// no merged window ends; win >= 17: 32-bit costs) and, for the others, once the job is large enough to fill its
+// coarse grid of 512..1024-thread blocks.
+bool strip_is_default(int win, int D, int cols, int rows, int n_pairs)
+{
+    if (D <= 64 || win < 4) return false;
+    if (win >= 17 || (win & 3) == 1) return true;
+    return (double)cols * rows * n_pairs >= 12e6;
 }
 
 // The whole device pipeline for n_pairs frames (or one band).  Input rows available: rows_in; output
@@ -751,9 +788,12 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     // zero frame: rows [nvalid, rows_out) entirely (SAD.cpp:31,34); columns >= cols-win are written
     // as zeros by the matcher itself.
     if (nvalid < rows_out) {
-        for (int n = 0; n < n_pairs; ++n)
-            HIPCHK(hipMemset2DAsync(dOut + (int64_t)n * pair_stride_out + (int64_t)nvalid * out_pitch, (size_t)out_pitch, 0,
-                                    (size_t)cols, (size_t)(rows_out - nvalid), st));
+        for (int z0 = nvalid; z0 < rows_out; z0 += 65535) {   // grid.y <= 65535
+            const int zn = rows_out - z0 < 65535 ? rows_out - z0 : 65535;
+            dim3 zg((cols + 1023) / 1024, zn, n_pairs);
+            hipLaunchKernelGGL(zero_rows_kernel, zg, dim3(256), 0, st, dOut, out_pitch, pair_stride_out, z0, zn, cols);
+        }
+        HIPCHK(hipGetLastError());
     }
     if (nvalid == 0) { snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "none"); return SADBM_OK; }
 
@@ -787,7 +827,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     const int strip_ng = D <= 64 ? 4 : D <= 128 ? 8 : 16;    // disparity groups of 16 per block (multiple of 4)
     strip_kernel_t sk = (win <= MAXWIN) ? pick_strip_kernel(win, strip::NS + strip_ng, MakeSeq<MAXWIN>::type()) : nullptr;
     if (sk && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL | SADBM_KERNEL_QUAD))) {
-        use_strip = (flags & SADBM_KERNEL_STRIP) != 0 || strip_is_default(win, D, cols);
+        use_strip = (flags & SADBM_KERNEL_STRIP) != 0 || strip_is_default(win, D, cols, nvalid, n_pairs);
         const char *e = getenv("SADBM_MATCHER");
         if (e && !(flags & SADBM_KERNEL_STRIP)) use_strip = strcmp(e, "strip") == 0 ? true : (strcmp(e, "quad") == 0 ? false : use_strip);
     }
@@ -798,9 +838,10 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         q.pitch = pitch; q.W = cols; q.nvalid = nvalid; q.win = win; q.D = D;
         q.out = dOut; q.out_pitch = out_pitch; q.out_stride = pair_stride_out; q.flags = flags; q.dword_store = p.dword_store;
         const int bx = (cols + strip::XBW - 1) / strip::XBW;
-        int TY = SADBM_TYMAX;
-        while (TY > 32 && (long)bx * ((nvalid + TY - 1) / TY) * n_pairs < SADBM_STRIP_MINBLOCKS) TY >>= 1;
-        { const char *e = getenv("SADBM_STRIP_TY"); if (e && atoi(e) >= 1) TY = atoi(e); }
+        // rows per block: a block is 64*NG threads and two blocks fit a CU only up to NG = 8, so the grid is a few
+        // hundred large blocks and its quantisation matters.  Minimise rounds x steps-per-block over band heights
+        // that fill whole rounds of block slots (a round whose CUs hold a single block runs ~0.65 as long).
+        int TY = strip_band_rows(bx, n_pairs, nvalid, win, q.NG);
         q.TY = TY;
         const int NSL = strip::NS + q.NG;
         const int ROWW = 4 * (strip::NS + 2) + 16 * strip::NS + 16 * (NSL + 3) + 64 * NSL;   // strip::Lay<NSL>::ROWW

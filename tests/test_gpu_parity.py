@@ -65,7 +65,7 @@ def test_both_disparity_chunkings(kc, win, D, monkeypatch):
     L, R = noise_pair(win + D, 70, 333, shift=9)
     exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
     ctx = oa.Context(0)
-    got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC, ctx=ctx).cpu().numpy()
+    got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_QUAD, ctx=ctx).cpu().numpy()
     assert ctx.last_kernel() == "sad_quad_lds_kernel<%d,%s>" % (win, kc)
     assert np.array_equal(got, exp)
 

@@ -1,0 +1,71 @@
+"""GPU parity of the strip matcher (sad_strip_kernel, forced with KERNEL_STRIP) against the oracle, and of the
+default matcher choice against both forced kernels.  Bit-exact bar; calls go through the C ABI."""
+import numpy as np
+import pytest
+import opencv_amd as oa
+import oracle
+from helpers import noise_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("win,D", [(15, 128), (7, 30), (9, 64), (7, 128), (21, 256), (4, 64), (5, 17), (6, 70), (8, 100), (12, 64), (13, 200),
+                                   (14, 64), (16, 129), (17, 64), (20, 64), (25, 256), (10, 1), (11, 16)])
+def test_strip_small(win, D):
+    for (H, W) in ((61, 203), (70, 333), (40, 600)):
+        for binary in (False, True):
+            L, R = noise_pair(win * 977 + D + W, H, W, shift=5, binary=binary)
+            exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
+            ctx = oa.Context(0)
+            got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
+            assert ctx.last_kernel() == "sad_strip_kernel<%d>" % win
+            bad = np.argwhere(got != exp)
+            assert bad.size == 0, (win, D, H, W, binary, len(bad), bad[:8], got[tuple(bad[0])], exp[tuple(bad[0])])
+
+
+def test_default_choice_matches_both_kernels():
+    """Whatever run_pipeline picks by default equals the forced quad and strip kernels (and the oracle)."""
+    L, R = oracle.rds(11, 900, 300, 6, 50, 0)
+    for win, D in ((9, 128), (15, 128), (21, 96), (7, 65), (13, 256)):
+        exp = oracle.box(L, R, win, D)
+        for fl in (0, oa.KERNEL_QUAD, oa.KERNEL_STRIP):
+            assert np.array_equal(oa.compute_device(dev(L), dev(R), win, D, fl).cpu().numpy(), exp), (win, D, fl)
+
+
+def test_strip_batch_bands_and_multichannel():
+    """Strip matcher through the batch entry point (pair stride), a row band, BGR input and an unaligned output view."""
+    import torch
+    n, H, W, win, D = 3, 90, 517, 15, 128
+    Ls, Rs = zip(*[oracle.rds(50 + i, W, H, 4 + i, 70 + i, 0) for i in range(n)])
+    out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, oa.KERNEL_STRIP).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), i
+    # band of a taller frame: rows 30..60 of pair 0 (needs input rows 30..74)
+    got = oa.compute_band_device(dev(Ls[0][30:74]), dev(Rs[0][30:74]), H, 30, 30, win, D, oa.KERNEL_STRIP).cpu().numpy()
+    assert np.array_equal(got, oracle.box(Ls[0], Rs[0], win, D)[30:60])
+    # 3-channel input (plane 0) and an output view that is not 4-byte aligned
+    L3 = np.stack([Ls[1], Ls[2], Ls[0]], -1); R3 = np.stack([Rs[1], Rs[2], Rs[0]], -1)
+    obuf = torch.zeros((H, W + 7), dtype=torch.uint8, device="cuda")
+    oa.compute_device(dev(L3), dev(R3), win, D, oa.KERNEL_STRIP, out=obuf[:, 3:3 + W])
+    assert np.array_equal(obuf[:, 3:3 + W].cpu().numpy(), oracle.box(Ls[1], Rs[1], win, D))
+    assert not obuf[:, :3].any() and not obuf[:, 3 + W:].any()
+
+
+def test_strip_full_size_4k_band():
+    """BASELINE config 3 at full size through the strip matcher: zero frame, planted disparities, a 150-row band vs the oracle."""
+    W, H, win, D = 3840, 2160, 15, 128
+    L, R = oracle.rds(3, W, H, 16, 96, 0)
+    ctx = oa.Context(0)
+    got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
+    assert ctx.last_kernel() == "sad_strip_kernel<15>"
+    assert not got[H - win:, :].any() and not got[:, W - win:].any()
+    assert (got[10, :16] == np.arange(1, 17)).all()
+    assert (got[100, 200:900] == 16).all() and (got[1000, 1200:2700] == 96).all()
+    r0, n = 1000, 150
+    exp = oracle.box(L[r0: r0 + n + win], R[r0: r0 + n + win], win, D, oracle.RAW_LOC)[:n]
+    assert np.array_equal(got[r0: r0 + n], exp)

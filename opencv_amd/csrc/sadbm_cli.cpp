@@ -1,58 +1,53 @@
 // sadbm_cli -- headless replacement for main() of /root/reference/SAD.cpp:63-82.
-//   sadbm_cli left.{ppm,pgm} right.{ppm,pgm} [--win 7] [--dsr 30] [-o disp.pgm]
-// Reads binary PGM (P5) / PPM (P6) files.  A PPM is stored RGB; cv::imread (SAD.cpp:65-66) returns BGR
-// and the matcher uses channel 0, so the planes are swapped to BGR on load -- channel 0 = blue.
-// No GUI (the reference's imshow/waitKey, SAD.cpp:71-79, are out of scope).
+//   sadbm_cli left.{png,ppm,pgm} right.{png,ppm,pgm} [--win 7] [--dsr 30] [--raw] [-o disparity.{pgm,png}]
+//   sadbm_cli --convert in.{png,ppm,pgm} out.{png,ppm,pgm}       (file I/O only, touches no GPU)
+// The reference loads left.png / right.png from the working directory with cv::imread (BGR, SAD.cpp:65-66),
+// calls getDisparity (SAD.cpp:76) and shows three HighGUI windows (SAD.cpp:71-79).  Here the two paths are
+// arguments, the files are decoded by imageio.hpp (channel 0 = blue, as imread gives), the disparity map is
+// written to a file, and there is no GUI.  Defaults are the reference's winSize = 7, DSR = 30 (SAD.cpp:9,11).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 
-#include "../../include/sadbm.hpp"
+#include "imageio.hpp"
 
-static bool read_pnm(const char *path, sadbm::Image &img)
+static int usage(const char *argv0)
 {
-    FILE *f = fopen(path, "rb");
-    if (!f) return false;
-    char magic[3] = {0};
-    int w = 0, h = 0, maxv = 0;
-    auto skip = [&]() { int c; while ((c = fgetc(f)) != EOF) { if (c == '#') { while ((c = fgetc(f)) != EOF && c != '\n') {} } else if (!isspace(c)) { ungetc(c, f); break; } } };
-    if (fscanf(f, "%2s", magic) != 1) { fclose(f); return false; }
-    skip(); if (fscanf(f, "%d", &w) != 1) { fclose(f); return false; }
-    skip(); if (fscanf(f, "%d", &h) != 1) { fclose(f); return false; }
-    skip(); if (fscanf(f, "%d", &maxv) != 1) { fclose(f); return false; }
-    fgetc(f);
-    int ch = !strcmp(magic, "P5") ? 1 : !strcmp(magic, "P6") ? 3 : 0;
-    if (!ch || maxv != 255 || w <= 0 || h <= 0) { fclose(f); return false; }
-    img = sadbm::Image(h, w, ch);
-    bool ok = fread(img.pix.data(), 1, img.pix.size(), f) == img.pix.size();
-    fclose(f);
-    if (ok && ch == 3)
-        for (size_t i = 0; i + 2 < img.pix.size(); i += 3) { uint8_t t = img.pix[i]; img.pix[i] = img.pix[i + 2]; img.pix[i + 2] = t; }   // RGB -> BGR
-    return ok;
+    fprintf(stderr, "usage: %s left right [--win 7] [--dsr 30] [--raw] [-o disparity.pgm|.png]\n"
+                    "       %s --convert in out\n", argv0, argv0);
+    return 2;
 }
 
 int main(int argc, char **argv)
 {
     const char *lp = nullptr, *rp = nullptr, *op = "disparity.pgm";
     int win = sadbm::kDefaultWinSize, dsr = sadbm::kDefaultDSR;
+    bool convert = false, raw = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--win") && i + 1 < argc) win = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--dsr") && i + 1 < argc) dsr = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-o") && i + 1 < argc) op = argv[++i];
+        else if (!strcmp(argv[i], "--convert")) convert = true;
+        else if (!strcmp(argv[i], "--raw")) raw = true;
+        else if (argv[i][0] == '-' && argv[i][1]) return usage(argv[0]);
         else if (!lp) lp = argv[i];
         else if (!rp) rp = argv[i];
+        else return usage(argv[0]);
     }
-    if (!lp || !rp) { fprintf(stderr, "usage: %s left.ppm right.ppm [--win 7] [--dsr 30] [-o disparity.pgm]\n", argv[0]); return 2; }
+    if (!lp || !rp) return usage(argv[0]);
+    std::string err;
     sadbm::Image L, R;
-    if (!read_pnm(lp, L) || !read_pnm(rp, R)) { fprintf(stderr, "cannot read %s / %s (binary PGM/PPM, maxval 255)\n", lp, rp); return 1; }
+    if (!sadbm_io::read_image(lp, L, err)) { fprintf(stderr, "%s: %s\n", lp, err.c_str()); return 1; }
+    if (convert) {
+        if (!sadbm_io::write_image(rp, L, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        printf("%s: %dx%d, %d channel(s)\n", rp, L.cols, L.rows, L.channels);
+        return 0;
+    }
+    if (!sadbm_io::read_image(rp, R, err)) { fprintf(stderr, "%s: %s\n", rp, err.c_str()); return 1; }
     try {
-        sadbm::Image d = sadbm::getDisparity(L, R, win, dsr);
-        FILE *f = fopen(op, "wb");
-        if (!f) { fprintf(stderr, "cannot write %s\n", op); return 1; }
-        fprintf(f, "P5\n%d %d\n255\n", d.cols, d.rows);
-        fwrite(d.pix.data(), 1, d.pix.size(), f);
-        fclose(f);
+        sadbm::Image d = sadbm::getDisparity(L.view(), R.view(), win, dsr, raw ? SADBM_RAW_LOC : 0u);
+        if (!sadbm_io::write_image(op, d, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
         printf("%s: %dx%d winSize=%d DSR=%d\n", op, d.cols, d.rows, win, dsr);
     } catch (const sadbm::Error &e) {
         fprintf(stderr, "%s\n", e.what());

@@ -47,6 +47,7 @@ extern "C" {
 #define SADBM_E_PARAM  -4   /* win<1, max_disp<1, max_disp>256, win>255 */
 #define SADBM_E_HIP    -5   /* HIP runtime error (sadbm_last_hip_error() has the text) */
 #define SADBM_E_ALLOC  -6   /* device memory allocation failed */
+#define SADBM_E_BUSY   -7   /* pipeline slot still in flight (wait on its ticket first) / unknown ticket */
 
 /* Host-memory image view; maps 1:1 onto cv::Mat {data, rows, cols, channels(), step[0]} (CV_8U only).
  * Replaces the `Mat &left, Mat &right` arguments of getDisparity (SAD.cpp:24). */
@@ -109,6 +110,25 @@ int sadbm_compute_batch_device(sadbm_ctx *ctx, const uint8_t *dL, const uint8_t 
                                int64_t pair_stride_in, int n_pairs, int rows, int cols, int channels,
                                int win, int max_disp, uint32_t flags, uint8_t *dOut,
                                int64_t out_pitch, int64_t pair_stride_out, void *stream);
+
+/* Streaming pipeline: `depth` slots, each with pinned host buffers, device buffers,
+ * its own stream and scratch, so H2D copy, matcher and D2H copy of consecutive frames overlap.  The reference
+ * processes one pair per program run (SAD.cpp:63-82) and has no counterpart; this is the caller loop a video
+ * user of getDisparity() would write.  All frames of a pipeline share rows/cols/channels/win/max_disp/flags.
+ *   slot = ticket % depth.  A slot may be refilled only after sadbm_pipeline_wait() on its previous ticket.
+ *   sadbm_pipeline_inputs : pinned input buffers of the next slot (fill them in place: zero-copy submit)
+ *   sadbm_pipeline_submit : enqueue H2D + getDisparity + D2H for that slot, returns its ticket at once;
+ *                           left/right may be NULL (buffers already filled) or images to copy in first
+ *   sadbm_pipeline_wait   : block until the ticket is done; *result points at the pinned rows x cols output
+ *                           (valid until the slot is submitted again); out, if not NULL, also receives a copy */
+typedef struct sadbm_pipeline sadbm_pipeline;
+int  sadbm_pipeline_create(int device, int depth, int rows, int cols, int channels, int win, int max_disp,
+                           uint32_t flags, sadbm_pipeline **out);
+void sadbm_pipeline_destroy(sadbm_pipeline *p);
+int  sadbm_pipeline_inputs(sadbm_pipeline *p, uint8_t **left, uint8_t **right, int64_t *step);
+int  sadbm_pipeline_submit(sadbm_pipeline *p, const sadbm_image *left, const sadbm_image *right, int64_t *ticket);
+int  sadbm_pipeline_wait(sadbm_pipeline *p, int64_t ticket, const uint8_t **result, int64_t *result_step,
+                         sadbm_plane *out);
 
 /* Introspection for benchmarks (no reference counterpart): name of the matcher kernel the last call
  * on this ctx launched, and HIP-event timing of the matcher launches between profile_begin and

@@ -5,7 +5,7 @@ include/sadbm.h.  There is no CPU fallback: every compute call goes through libs
 gfx950) and raises if the library or a GPU is missing.
 """
 from .stereo import (  # noqa: F401
-    RAW_LOC, FORCE_GENERIC, KERNEL_GLOBAL, KERNEL_STRIP, KERNEL_QUAD, SadbmError, Context, getDisparity, get_disparity_host, library_path,
+    RAW_LOC, FORCE_GENERIC, KERNEL_GLOBAL, KERNEL_STRIP, KERNEL_QUAD, SadbmError, Context, Pipeline, getDisparity, get_disparity_host, library_path,
     load_library, build_library, compute_device, compute_band_device, compute_batch_device,
     DEFAULT_WIN_SIZE, DEFAULT_DSR,
 )

@@ -700,6 +700,8 @@ struct sadbm_ctx {
     size_t stage_in_cap;
     uint8_t *stage_out;
     size_t stage_out_cap;
+    uint8_t *pin_in, *pin_out;   // pinned host staging of the host API (pageable -> device copies are ~20x slower)
+    size_t pin_in_cap, pin_out_cap;
     char last_kernel[64];
     // profiling: event triples (before prep, before matcher, after matcher) per pipeline run
     hipEvent_t *ev;
@@ -722,6 +724,17 @@ int grow(uint8_t **buf, size_t *cap, size_t need)
     size_t want = need + need / 8 + 4096;
     hipError_t e = hipMalloc((void **)buf, want);
     if (e != hipSuccess) { *buf = nullptr; hip_fail(e, "hipMalloc"); return SADBM_E_ALLOC; }
+    *cap = want;
+    return SADBM_OK;
+}
+
+int grow_pinned(uint8_t **buf, size_t *cap, size_t need)
+{
+    if (*cap >= need) return SADBM_OK;
+    if (*buf) { hipError_t e = hipHostFree(*buf); *buf = nullptr; *cap = 0; if (e != hipSuccess) return hip_fail(e, "hipHostFree"); }
+    size_t want = need + need / 8 + 4096;
+    hipError_t e = hipHostMalloc((void **)buf, want, hipHostMallocDefault);
+    if (e != hipSuccess) { *buf = nullptr; hip_fail(e, "hipHostMalloc"); return SADBM_E_ALLOC; }
     *cap = want;
     return SADBM_OK;
 }
@@ -915,6 +928,7 @@ const char *sadbm_strerror(int code)
     case SADBM_E_PARAM: return "bad parameter (need 1<=win<=255, 1<=max_disp<=256)";
     case SADBM_E_HIP: return "HIP runtime error";
     case SADBM_E_ALLOC: return "device memory allocation failed";
+    case SADBM_E_BUSY: return "pipeline slot still in flight, or ticket unknown";
     default: return "unknown error";
     }
 }
@@ -948,6 +962,8 @@ void sadbm_destroy(sadbm_ctx *c)
     if (c->planes) (void)hipFree(c->planes);
     if (c->stage_in) (void)hipFree(c->stage_in);
     if (c->stage_out) (void)hipFree(c->stage_out);
+    if (c->pin_in) (void)hipHostFree(c->pin_in);
+    if (c->pin_out) (void)hipHostFree(c->pin_out);
     for (int i = 0; i < 3 * c->ev_cap; ++i) (void)hipEventDestroy(c->ev[i]);
     delete[] c->ev;
     if (g_tls_ctx == c) g_tls_ctx = nullptr;
@@ -1070,15 +1086,24 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
     if (rc) return rc;
     rc = grow(&ctx->stage_out, &ctx->stage_out_cap, pout * rows);
     if (rc) return rc;
+    rc = grow_pinned(&ctx->pin_in, &ctx->pin_in_cap, 2 * pin * rows);
+    if (rc) return rc;
+    rc = grow_pinned(&ctx->pin_out, &ctx->pin_out_cap, pout * rows);
+    if (rc) return rc;
     uint8_t *dL = ctx->stage_in, *dR = ctx->stage_in + pin * rows;
+    uint8_t *hL = ctx->pin_in, *hR = ctx->pin_in + pin * rows;
     hipStream_t st = ctx->stream;
-    HIPCHK(hipMemcpy2DAsync(dL, pin, left->data, (size_t)left->step, rowb, rows, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpy2DAsync(dR, pin, right->data, (size_t)right->step, rowb, rows, hipMemcpyHostToDevice, st));
+    // caller's (pageable, strided) rows -> pinned staging -> device; the R copy overlaps the L transfer
+    for (int y = 0; y < rows; ++y) memcpy(hL + (size_t)y * pin, left->data + (int64_t)y * left->step, rowb);
+    HIPCHK(hipMemcpyAsync(dL, hL, pin * rows, hipMemcpyHostToDevice, st));
+    for (int y = 0; y < rows; ++y) memcpy(hR + (size_t)y * pin, right->data + (int64_t)y * right->step, rowb);
+    HIPCHK(hipMemcpyAsync(dR, hR, pin * rows, hipMemcpyHostToDevice, st));
     rc = sadbm_compute_device(ctx, dL, (int64_t)pin, dR, (int64_t)pin, rows, cols, ch, win, max_disp, flags, ctx->stage_out,
                               (int64_t)pout, st);
     if (rc) return rc;
-    HIPCHK(hipMemcpy2DAsync(out->data, (size_t)out->step, ctx->stage_out, pout, (size_t)cols, rows, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->pin_out, ctx->stage_out, pout * rows, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    for (int y = 0; y < rows; ++y) memcpy(out->data + (int64_t)y * out->step, ctx->pin_out + (size_t)y * pout, (size_t)cols);
     return SADBM_OK;
 }
 
@@ -1090,6 +1115,149 @@ int sadbm_get_disparity(const sadbm_image *left, const sadbm_image *right, int w
         if (rc) return rc;
     }
     return sadbm_get_disparity_ctx(g_tls_ctx, left, right, win, max_disp, flags, out);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// streaming pipeline (include/sadbm.h): depth x { pinned in/out, device in/out, ctx with its own stream }
+// ---------------------------------------------------------------------------------------------
+struct sadbm_pipeline {
+    int device, depth, rows, cols, channels, win, max_disp;
+    uint32_t flags;
+    size_t in_step, out_step;          // bytes per row of the pinned / device buffers (256-byte multiples)
+    int64_t next;                      // next ticket
+    struct Slot {
+        sadbm_ctx *ctx;
+        uint8_t *hL, *hR, *hO;         // pinned host
+        uint8_t *dL, *dR, *dO;         // device
+        hipEvent_t done;
+        int64_t ticket;                // ticket in flight or finished, -1 = never used
+        bool in_flight;
+    } *slots;
+};
+
+extern "C" {
+
+void sadbm_pipeline_destroy(sadbm_pipeline *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (int i = 0; i < p->depth && p->slots; ++i) {
+        sadbm_pipeline::Slot &s = p->slots[i];
+        if (s.ctx) { (void)hipStreamSynchronize(s.ctx->stream); }
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (s.hL) (void)hipHostFree(s.hL);
+        if (s.hR) (void)hipHostFree(s.hR);
+        if (s.hO) (void)hipHostFree(s.hO);
+        if (s.dL) (void)hipFree(s.dL);
+        if (s.dR) (void)hipFree(s.dR);
+        if (s.dO) (void)hipFree(s.dO);
+        sadbm_destroy(s.ctx);
+    }
+    delete[] p->slots;
+    delete p;
+}
+
+int sadbm_pipeline_create(int device, int depth, int rows, int cols, int channels, int win, int max_disp, uint32_t flags,
+                          sadbm_pipeline **out)
+{
+    if (!out) return SADBM_E_NULL;
+    *out = nullptr;
+    int rc = check_params(rows, cols, channels, win, max_disp, flags);
+    if (rc) return rc;
+    if (depth < 1 || depth > 16 || rows < 1 || cols < 1) return SADBM_E_PARAM;
+    sadbm_pipeline *p = new (std::nothrow) sadbm_pipeline();
+    if (!p) return SADBM_E_ALLOC;
+    memset(p, 0, sizeof(*p));
+    p->device = device; p->depth = depth; p->rows = rows; p->cols = cols; p->channels = channels;
+    p->win = win; p->max_disp = max_disp; p->flags = flags;
+    p->in_step = ((size_t)cols * channels + 255) & ~(size_t)255;
+    p->out_step = ((size_t)cols + 255) & ~(size_t)255;
+    p->slots = new (std::nothrow) sadbm_pipeline::Slot[depth];
+    if (!p->slots) { delete p; return SADBM_E_ALLOC; }
+    memset(p->slots, 0, sizeof(sadbm_pipeline::Slot) * depth);
+    for (int i = 0; i < depth; ++i) {
+        sadbm_pipeline::Slot &s = p->slots[i];
+        s.ticket = -1;
+        rc = sadbm_create(device, &s.ctx);
+        hipError_t e = hipSuccess;
+        if (!rc) e = hipHostMalloc((void **)&s.hL, p->in_step * rows, hipHostMallocDefault);
+        if (!rc && e == hipSuccess) e = hipHostMalloc((void **)&s.hR, p->in_step * rows, hipHostMallocDefault);
+        if (!rc && e == hipSuccess) e = hipHostMalloc((void **)&s.hO, p->out_step * rows, hipHostMallocDefault);
+        if (!rc && e == hipSuccess) e = hipMalloc((void **)&s.dL, p->in_step * rows);
+        if (!rc && e == hipSuccess) e = hipMalloc((void **)&s.dR, p->in_step * rows);
+        if (!rc && e == hipSuccess) e = hipMalloc((void **)&s.dO, p->out_step * rows);
+        if (!rc && e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+        if (rc || e != hipSuccess) {
+            if (!rc) { hip_fail(e, "pipeline allocation"); rc = SADBM_E_ALLOC; }
+            sadbm_pipeline_destroy(p);
+            return rc;
+        }
+    }
+    *out = p;
+    return SADBM_OK;
+}
+
+int sadbm_pipeline_inputs(sadbm_pipeline *p, uint8_t **left, uint8_t **right, int64_t *step)
+{
+    if (!p || !left || !right || !step) return SADBM_E_NULL;
+    sadbm_pipeline::Slot &s = p->slots[p->next % p->depth];
+    if (s.in_flight) return SADBM_E_BUSY;
+    *left = s.hL; *right = s.hR; *step = (int64_t)p->in_step;
+    return SADBM_OK;
+}
+
+int sadbm_pipeline_submit(sadbm_pipeline *p, const sadbm_image *left, const sadbm_image *right, int64_t *ticket)
+{
+    if (!p || !ticket) return SADBM_E_NULL;
+    if ((left == nullptr) != (right == nullptr)) return SADBM_E_NULL;
+    sadbm_pipeline::Slot &s = p->slots[p->next % p->depth];
+    if (s.in_flight) return SADBM_E_BUSY;
+    const size_t rowb = (size_t)p->cols * p->channels;
+    if (left) {
+        if (left->rows != p->rows || left->cols != p->cols || left->channels != p->channels) return SADBM_E_SIZE;
+        if (right->channels != p->channels) return SADBM_E_TYPE;
+        if (right->rows < p->rows || right->cols < p->cols) return SADBM_E_SIZE;
+        if (!left->data || !right->data) return SADBM_E_NULL;
+        if (left->step < (int64_t)rowb || right->step < (int64_t)rowb) return SADBM_E_SIZE;
+        for (int y = 0; y < p->rows; ++y) {
+            memcpy(s.hL + (size_t)y * p->in_step, left->data + (int64_t)y * left->step, rowb);
+            memcpy(s.hR + (size_t)y * p->in_step, right->data + (int64_t)y * right->step, rowb);
+        }
+    }
+    HIPCHK(hipSetDevice(p->device));
+    hipStream_t st = s.ctx->stream;
+    HIPCHK(hipMemcpy2DAsync(s.dL, p->in_step, s.hL, p->in_step, rowb, p->rows, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpy2DAsync(s.dR, p->in_step, s.hR, p->in_step, rowb, p->rows, hipMemcpyHostToDevice, st));
+    int rc = sadbm_compute_device(s.ctx, s.dL, (int64_t)p->in_step, s.dR, (int64_t)p->in_step, p->rows, p->cols, p->channels,
+                                  p->win, p->max_disp, p->flags, s.dO, (int64_t)p->out_step, st);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy2DAsync(s.hO, p->out_step, s.dO, p->out_step, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(s.done, st));
+    s.ticket = p->next; s.in_flight = true;
+    *ticket = p->next++;
+    return SADBM_OK;
+}
+
+int sadbm_pipeline_wait(sadbm_pipeline *p, int64_t ticket, const uint8_t **result, int64_t *result_step, sadbm_plane *out)
+{
+    if (!p) return SADBM_E_NULL;
+    if (ticket < 0 || ticket >= p->next) return SADBM_E_BUSY;
+    sadbm_pipeline::Slot &s = p->slots[ticket % p->depth];
+    if (s.ticket != ticket) return SADBM_E_BUSY;              // the slot was reused: the result is gone
+    if (s.in_flight) {
+        HIPCHK(hipEventSynchronize(s.done));
+        s.in_flight = false;
+    }
+    if (result) *result = s.hO;
+    if (result_step) *result_step = (int64_t)p->out_step;
+    if (out) {
+        if (!out->data) return SADBM_E_NULL;
+        if (out->rows != p->rows || out->cols != p->cols || out->step < p->cols) return SADBM_E_SIZE;
+        for (int y = 0; y < p->rows; ++y) memcpy(out->data + (int64_t)y * out->step, s.hO + (size_t)y * p->out_step, (size_t)p->cols);
+    }
+    return SADBM_OK;
 }
 
 }  // extern "C"

@@ -90,6 +90,14 @@ def load_library():
     L.sadbm_last_kernel_name.restype = ctypes.c_char_p
     L.sadbm_profile_begin.argtypes = [vp, i32]
     L.sadbm_profile_end.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    L.sadbm_pipeline_create.argtypes = [i32, i32, i32, i32, i32, i32, i32, u32, ctypes.POINTER(vp)]
+    L.sadbm_pipeline_destroy.argtypes = [vp]
+    L.sadbm_pipeline_destroy.restype = None
+    L.sadbm_pipeline_inputs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    L.sadbm_pipeline_submit.argtypes = [vp, ctypes.POINTER(_Image), ctypes.POINTER(_Image), ctypes.POINTER(i64)]
+    L.sadbm_pipeline_wait.argtypes = [vp, i64, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(_Plane)]
+    for name in ("sadbm_pipeline_create", "sadbm_pipeline_inputs", "sadbm_pipeline_submit", "sadbm_pipeline_wait"):
+        getattr(L, name).restype = i32
     for name in ("sadbm_profile_begin", "sadbm_profile_end", "sadbm_create", "sadbm_get_disparity", "sadbm_get_disparity_ctx", "sadbm_compute_device",
                  "sadbm_compute_band_device", "sadbm_compute_batch_device"):
         getattr(L, name).restype = i32
@@ -298,3 +306,66 @@ def getDisparity(left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags=0
     except ImportError:
         pass
     return get_disparity_host(left, right, winSize, DSR, flags)
+
+
+class Pipeline:
+    """Streaming getDisparity over host frames (sadbm_pipeline_*): `depth` slots with pinned buffers and their own
+    streams, so the H2D copy, the matcher and the D2H copy of consecutive frames overlap.
+
+        pipe = Pipeline(rows, cols, depth=3)
+        t = pipe.submit(left, right)          # numpy u8 frames; returns a ticket at once
+        disp = pipe.wait(t)                   # numpy view of the pinned result (valid until the slot is reused)
+    """
+
+    def __init__(self, rows, cols, channels=1, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags=0, depth=3, device=0):
+        L = load_library()
+        h = ctypes.c_void_p()
+        _check(L.sadbm_pipeline_create(int(device), int(depth), int(rows), int(cols), int(channels), int(winSize), int(DSR),
+                                       int(flags), ctypes.byref(h)))
+        self._h = h
+        self.rows, self.cols, self.channels, self.depth = int(rows), int(cols), int(channels), int(depth)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().sadbm_pipeline_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def inputs(self):
+        """(left, right) numpy views of the next slot's pinned input buffers: fill them, then submit()."""
+        import numpy as np
+        lp, rp, step = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
+        _check(load_library().sadbm_pipeline_inputs(self._h, ctypes.byref(lp), ctypes.byref(rp), ctypes.byref(step)))
+        rowb = self.cols * self.channels
+
+        def view(ptr):
+            buf = (ctypes.c_uint8 * (step.value * self.rows)).from_address(ptr.value)
+            a = np.frombuffer(buf, dtype=np.uint8).reshape(self.rows, step.value)[:, :rowb]
+            return a if self.channels == 1 else a.reshape(self.rows, self.cols, self.channels)
+
+        return view(lp), view(rp)
+
+    def submit(self, left=None, right=None):
+        """Enqueue one frame; left/right None = the pinned inputs() were filled in place."""
+        t = ctypes.c_int64()
+        if left is None:
+            _check(load_library().sadbm_pipeline_submit(self._h, None, None, ctypes.byref(t)))
+            return t.value
+        left, right = _host_views(left, right)                 # (rows, cols, ch) u8 views; kept alive until the call returns
+        li = _Image(left.ctypes.data, left.shape[0], left.shape[1], left.shape[2], left.strides[0])
+        ri = _Image(right.ctypes.data, right.shape[0], right.shape[1], right.shape[2], right.strides[0])
+        _check(load_library().sadbm_pipeline_submit(self._h, ctypes.byref(li), ctypes.byref(ri), ctypes.byref(t)))
+        return t.value
+
+    def wait(self, ticket, copy=False):
+        import numpy as np
+        ptr, step = ctypes.c_void_p(), ctypes.c_int64()
+        _check(load_library().sadbm_pipeline_wait(self._h, int(ticket), ctypes.byref(ptr), ctypes.byref(step), None))
+        buf = (ctypes.c_uint8 * (step.value * self.rows)).from_address(ptr.value)
+        a = np.frombuffer(buf, dtype=np.uint8).reshape(self.rows, step.value)[:, :self.cols]
+        return a.copy() if copy else a

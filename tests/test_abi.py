@@ -30,8 +30,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_strerror_covers_codes():
     lib = oa.load_library()
-    texts = {lib.sadbm_strerror(c) for c in range(0, -7, -1)}
-    assert len(texts) == 7
+    texts = {lib.sadbm_strerror(c) for c in range(0, -8, -1)}
+    assert len(texts) == 8
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -5,7 +5,8 @@ Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distr
 per GPU).  A step = one pass of the hot path (sadbm_compute_batch_device: plane prep + matcher +
 zero frame) over one batch of synthetic stereo pairs that are already resident in HBM.  Default
 workload = BASELINE.json configs[2], the config the metric is quoted on: rds(3,3840,2160,16,96),
-15x15 window, D=128.  Multi-GPU = batch data parallelism: every rank processes its own batch, no
+15x15 window, D=128, a batch of 16 distinct frames per step (the grid of 512-thread blocks needs a few thousand
+blocks to balance; 2 frames per step reach 3.1, 16 reach 4.0 Tdisp-evals/s).  Multi-GPU = batch data parallelism: every rank processes its own batch, no
 data-path collective (weak scaling); value = evals of all ranks / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).
@@ -21,10 +22,10 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (W, H, win, D, rds seed, d_bg, d_fg, pairs per step)
-    "cfg2_1080p_w9_d64": (1920, 1080, 9, 64, 2, 8, 40, 4),
-    "cfg2b_1080p_w9_d128": (1920, 1080, 9, 128, 2, 8, 40, 4),
-    "cfg3_4k_w15_d128": (3840, 2160, 15, 128, 3, 16, 96, 2),
-    "cfg4_8k_w21_d256": (7680, 4320, 21, 256, 4, 32, 200, 1),
+    "cfg2_1080p_w9_d64": (1920, 1080, 9, 64, 2, 8, 40, 16),
+    "cfg2b_1080p_w9_d128": (1920, 1080, 9, 128, 2, 8, 40, 16),
+    "cfg3_4k_w15_d128": (3840, 2160, 15, 128, 3, 16, 96, 16),
+    "cfg4_8k_w21_d256": (7680, 4320, 21, 256, 4, 32, 200, 4),
     "cfg5_kitti_w7_d128": (1242, 375, 7, 128, 1000, 5, 60, 64),
 }
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec

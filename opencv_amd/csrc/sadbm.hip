@@ -82,24 +82,33 @@ struct Params {
 
 // ---------------------------------------------------------------------------------------------
 // 1. plane preparation: dst[y][PADL + x] = src[y][x*ch] (channel 0), zero elsewhere.
-//    One thread writes one aligned dword of dst.
+//    One thread writes 16 aligned bytes of dst.
 // ---------------------------------------------------------------------------------------------
+typedef uint32_t prep_u32x4u __attribute__((ext_vector_type(4), aligned(1)));
 __global__ void __launch_bounds__(256) prep_plane_kernel(const uint8_t *__restrict__ src, int64_t step, int64_t src_stride,
                                                           int ch, int rows, int cols, uint8_t *__restrict__ dst,
                                                           int pitch, int64_t dst_stride)
 {
-    int wi = blockIdx.x * 256 + threadIdx.x;
-    int y = blockIdx.y;
-    if (wi * 4 >= pitch || y >= rows) return;
+    // one thread writes 16 aligned bytes of dst (pitch is a multiple of 128)
+    const int wi = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (wi * 16 >= pitch || y >= rows) return;
     const uint8_t *s = src + (int64_t)blockIdx.z * src_stride + (int64_t)y * step;
-    uint32_t v = 0;
-    int xb = wi * 4 - PADL;
+    const int xb = wi * 16 - PADL;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ch == 1 && xb >= 0 && xb + 16 <= cols) {
+        const prep_u32x4u q = *(const prep_u32x4u *)(s + xb);
+        v = make_uint4(q.x, q.y, q.z, q.w);
+    } else if (xb + 16 > 0 && xb < cols) {
+        uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        int x = xb + b;
-        if (x >= 0 && x < cols) v |= (uint32_t)s[(int64_t)x * ch] << (8 * b);
+        for (int b = 0; b < 16; ++b) {
+            const int x = xb + b;
+            if (x >= 0 && x < cols) w[b >> 2] |= (uint32_t)s[(int64_t)x * ch] << (8 * (b & 3));
+        }
+        v = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    *(uint32_t *)(dst + (int64_t)blockIdx.z * dst_stride + (int64_t)y * pitch + wi * 4) = v;
+    *(uint4 *)(dst + (int64_t)blockIdx.z * dst_stride + (int64_t)y * pitch + wi * 16) = v;
 }
 
 // The zero frame of SAD.cpp:31,34: output rows [row0, row0+nrows) of every pair (any pitch / alignment).
@@ -822,7 +831,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     const bool prof = ctx->prof_on && ctx->ev_n < ctx->ev_cap;
     hipEvent_t *ev = prof ? ctx->ev + 3 * ctx->ev_n : nullptr;
     if (prof) HIPCHK(hipEventRecord(ev[0], st));
-    dim3 pg((pitch / 4 + 255) / 256, need_rows, n_pairs);
+    dim3 pg((pitch / 16 + 255) / 256, need_rows, n_pairs);
     hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dL, pitchL, pair_stride_in, channels, need_rows, cols, pL, pitch, (int64_t)(2 * plane_bytes));
     hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dR, pitchR, pair_stride_in, channels, need_rows, cols, pR, pitch, (int64_t)(2 * plane_bytes));
     HIPCHK(hipGetLastError());

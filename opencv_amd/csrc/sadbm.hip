@@ -659,25 +659,27 @@ static quad_kernel_t pick_quad_lds_kernel(int win, int kc, Seq<I...>)
 #ifndef SADBM_STRIP_WINS
 #define SADBM_STRIP_WINS 25
 #endif
+// host copies of the kernel's compile-time geometry: staging passes per row image, dwords per row image
 template <int WIN>
-static int strip_passes_one(int nsl)
+static void strip_geometry_one(int nsl, int *pr, int *roww)
 {
     if constexpr (WIN >= 4 && WIN <= SADBM_STRIP_WINS && strip::SG<WIN>::ok) {
         using SP = strip::StagePlan<WIN>;
-        return ((SP::n_single(nsl) + 63) >> 6) + ((SP::n_double(nsl) + 63) >> 6);
+        *pr = ((SP::n_single(nsl) + 63) >> 6) + ((SP::n_double(nsl) + 63) >> 6);
+        *roww = nsl == strip::NS + 4 ? strip::Lay<WIN, strip::NS + 4>::ROWW
+              : nsl == strip::NS + 8 ? strip::Lay<WIN, strip::NS + 8>::ROWW : strip::Lay<WIN, strip::NS + 16>::ROWW;
     } else {
-        (void)nsl;
-        return 0;
+        (void)nsl; *pr = 0; *roww = 0;
     }
 }
 template <int... I>
-static int strip_passes_table(int win, int nsl, Seq<I...>)
+static void strip_geometry_table(int win, int nsl, int *pr, int *roww, Seq<I...>)
 {
-    typedef int (*fn_t)(int);
-    static const fn_t table[] = { strip_passes_one<I + 1>... };
-    return table[win - 1](nsl);
+    typedef void (*fn_t)(int, int *, int *);
+    static const fn_t table[] = { strip_geometry_one<I + 1>... };
+    table[win - 1](nsl, pr, roww);
 }
-static int strip_passes_per_row(int win, int nsl) { return strip_passes_table(win, nsl, MakeSeq<MAXWIN>::type()); }
+static void strip_geometry(int win, int nsl, int *pr, int *roww) { strip_geometry_table(win, nsl, pr, roww, MakeSeq<MAXWIN>::type()); }
 
 template <int WIN, int NSLM>
 static strip_kernel_t strip_entry()
@@ -866,8 +868,8 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         int TY = strip_band_rows(bx, n_pairs, nvalid, win, q.NG);
         q.TY = TY;
         const int NSL = strip::NS + q.NG;
-        const int ROWW = 4 * (strip::NS + 2) + 16 * strip::NS + 16 * (NSL + 3) + 64 * NSL;   // strip::Lay<NSL>::ROWW
-        const int PR = strip_passes_per_row(win, NSL);
+        int PR = 0, ROWW = 0;
+        strip_geometry(win, NSL, &PR, &ROWW);
         const size_t lds = (size_t)(4 * ROWW + 4 * 64 * PR + 2 * 4 * 64) * 4;
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         dim3 g(bx, (nvalid + TY - 1) / TY, n_pairs);

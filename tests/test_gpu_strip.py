@@ -69,3 +69,29 @@ def test_strip_full_size_4k_band():
     r0, n = 1000, 150
     exp = oracle.box(L[r0: r0 + n + win], R[r0: r0 + n + win], win, D, oracle.RAW_LOC)[:n]
     assert np.array_equal(got[r0: r0 + n], exp)
+
+
+@pytest.mark.parametrize("shape", [(9, 300), (300, 9), (40, 17), (8, 8), (16, 50), (50, 16), (1, 1), (33, 129), (20, 255), (20, 257), (20, 513)])
+def test_strip_small_and_degenerate_shapes(shape):
+    """Shapes around the strip (16), block (256) and window sizes, W < D, W <= win, H <= win -- forced strip matcher."""
+    H, W = shape
+    L, R = noise_pair(H * 31 + W, H, W)
+    for win, D in ((7, 30), (4, 64), (9, 256), (15, 100), (21, 65)):
+        exp = oracle.literal(L, R, win, D)
+        got = oa.get_disparity_host(L, R, win, D, oa.KERNEL_STRIP)
+        assert np.array_equal(got, exp), (shape, win, D)
+
+
+def test_strip_constant_identical_and_binary_ties():
+    c1 = np.full((40, 300), 10, np.uint8)
+    c2 = np.full((40, 300), 200, np.uint8)
+    assert np.array_equal(oa.get_disparity_host(c1, c2, 15, 128, oa.RAW_LOC | oa.KERNEL_STRIP), oracle.literal(c1, c2, 15, 128, oracle.RAW_LOC))   # K2
+    L, R = noise_pair(3, 40, 300)
+    assert not oa.get_disparity_host(L, L, 9, 128, oa.RAW_LOC | oa.KERNEL_STRIP).any()                                                          # K1
+    z = np.zeros((40, 300), np.uint8)                          # pixel value 0 everywhere: every cost is 0, first minimum = 0
+    assert not oa.get_disparity_host(z, z, 13, 200, oa.RAW_LOC | oa.KERNEL_STRIP).any()
+    Lb, Rb = oracle.rds(1, 320, 240, 4, 20, 1)                 # binary dots: heavy ties (K9)
+    assert np.array_equal(oa.get_disparity_host(Lb, Rb, 9, 128, oa.KERNEL_STRIP), oracle.box(Lb, Rb, 9, 128))
+    big = np.full((30, 400), 255, np.uint8)                    # largest costs: 16-bit halves must not overflow (16x16x255 = 65280)
+    zero = np.zeros((30, 400), np.uint8)
+    assert np.array_equal(oa.get_disparity_host(big, zero, 16, 128, oa.RAW_LOC | oa.KERNEL_STRIP), oracle.literal(big, zero, 16, 128, oracle.RAW_LOC))

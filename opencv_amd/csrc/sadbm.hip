@@ -787,15 +787,14 @@ int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG)
     return best_ty;
 }
 
-// Default matcher choice, from tools/sweep.py and bench.py on MI355X (profiles/r01e_*): the strip matcher needs
-// >= 65 disparities to amortise its staged R words; it wins for windows the quad matcher handles badly (win = 1 mod 4:
-// no merged window ends; win >= 17: 32-bit costs) and, for the others, once the job is large enough to fill its
-// coarse grid of 512..1024-thread blocks.
+// Default matcher choice, from tools/sweep.py and bench.py on MI355X (profiles/r01h_sweep_*.txt): the strip matcher
+// needs >= 65 disparities to amortise its staged R words; above that it wins from single 640x480 frames (0.53-0.61x
+// the quad matcher's time) to batches of 4K frames (0.79-0.85x); the worst cases measured are mid-size batches with
+// win = 3 mod 4 (1080p x 4: 1.02-1.08x).  D <= 64: the quad matcher (strip 0.96-1.26x).
 bool strip_is_default(int win, int D, int cols, int rows, int n_pairs)
 {
-    if (D <= 64 || win < 4) return false;
-    if (win >= 17 || (win & 3) == 1) return true;
-    return (double)cols * rows * n_pairs >= 12e6;
+    (void)cols; (void)rows; (void)n_pairs;
+    return D > 64 && win >= 4;
 }
 
 // The whole device pipeline for n_pairs frames (or one band).  Input rows available: rows_in; output

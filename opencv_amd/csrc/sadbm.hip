@@ -869,7 +869,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         const int NSL = strip::NS + q.NG;
         int PR = 0, ROWW = 0;
         strip_geometry(win, NSL, &PR, &ROWW);
-        const size_t lds = (size_t)(4 * ROWW + 4 * 64 * PR + 2 * 4 * 64) * 4;
+        const size_t lds = (size_t)(4 * ROWW + 3 * 64 * PR + 2 * 4 * 64) * 4;
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         dim3 g(bx, (nvalid + TY - 1) / TY, n_pairs);
         hipLaunchKernelGGL(sk, g, dim3(64 * q.NG), lds, st, q);

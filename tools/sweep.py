@@ -12,7 +12,7 @@ dL = torch.from_numpy(np.stack([L] * pairs)).cuda(); dR = torch.from_numpy(np.st
 dO = torch.empty((pairs, H, W), dtype=torch.uint8, device="cuda")
 ctx = oa.Context(0)
 print("W H pairs", W, H, pairs)
-for D in (32, 64, 96, 128, 192, 256):
+for D in [int(x) for x in os.environ.get("SWEEP_D", "32,64,96,128,192,256").split(",")]:
     for win in (5, 7, 9, 11, 13, 15, 17, 21, 25):
         ms = {}
         for name, fl in (("quad", oa.KERNEL_QUAD), ("strip", oa.KERNEL_STRIP)):

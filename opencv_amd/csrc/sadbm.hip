@@ -768,7 +768,7 @@ int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG)
 {
     const char *e = getenv("SADBM_STRIP_TY");
     if (e && atoi(e) >= 1) return atoi(e);
-    const long cus = 256, per_cu = NG <= 8 ? 2 : 1, slots = cus * per_cu;
+    const long cus = 256, per_cu = 16 / NG, slots = cus * per_cu;   // 16 waves per CU at 128 VGPRs; a block is NG waves
     const long cols = (long)bx * n_pairs;
     double best = 1e30; int best_ty = nvalid < 128 ? (nvalid > 0 ? nvalid : 1) : 128;
     for (long m = 1; m <= 24; ++m) {
@@ -780,7 +780,7 @@ int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG)
         const long rnby = (nvalid + ty - 1) / ty, blocks = cols * rnby;
         const long full = blocks / slots, rem = blocks - full * slots;
         double rounds = (double)full;
-        if (rem > 0) rounds += (per_cu == 2 && rem <= cus) ? 0.65 : 1.0;
+        if (rem > 0) rounds += (per_cu >= 2 && rem <= slots / 2) ? 0.65 : 1.0;
         const double cost = (rounds + 0.4) * (ty + win - 1);   // +0.4: finer grids balance better (measured, tools/dbg/ty.sh)
         if (cost < best) { best = cost; best_ty = ty; }
     }
@@ -790,11 +790,13 @@ int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG)
 // Default matcher choice, from tools/sweep.py and bench.py on MI355X (profiles/r01h_sweep_*.txt): the strip matcher
 // needs >= 65 disparities to amortise its staged R words; above that it wins from single 640x480 frames (0.53-0.61x
 // the quad matcher's time) to batches of 4K frames (0.79-0.85x); the worst cases measured are mid-size batches with
-// win = 3 mod 4 (1080p x 4: 1.02-1.08x).  D <= 64: the quad matcher (strip 0.96-1.26x).
+// win = 3 mod 4 (1080p x 4: 1.02-1.08x).  At 64 disparities the two are within 10 % of each other; below ~48 the
+// quad matcher wins (strip 1.0-1.4x).
 bool strip_is_default(int win, int D, int cols, int rows, int n_pairs)
 {
     (void)cols; (void)rows; (void)n_pairs;
-    return D > 64 && win >= 4;
+    if (win < 4) return false;
+    return D > 64 || (D > 48 && win >= 9);                     // 49..64 disparities: 0.89-1.00x for win >= 9, 1.04-1.07x for win = 7
 }
 
 // The whole device pipeline for n_pairs frames (or one band).  Input rows available: rows_in; output

@@ -714,6 +714,7 @@ struct sadbm_ctx {
     uint8_t *pin_in, *pin_out;   // pinned host staging of the host API (pageable -> device copies are ~20x slower)
     size_t pin_in_cap, pin_out_cap;
     char last_kernel[64];
+    int cus;                     // compute units of the device (grid shaping)
     // profiling: event triples (before prep, before matcher, after matcher) per pipeline run
     hipEvent_t *ev;
     int ev_cap, ev_n, prof_on;
@@ -764,11 +765,11 @@ int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 #ifndef SADBM_STRIP_MINBLOCKS
 #define SADBM_STRIP_MINBLOCKS 500
 #endif
-int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG)
+int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG, int n_cus)
 {
     const char *e = getenv("SADBM_STRIP_TY");
     if (e && atoi(e) >= 1) return atoi(e);
-    const long cus = 256, per_cu = 16 / NG, slots = cus * per_cu;   // 16 waves per CU at 128 VGPRs; a block is NG waves
+    const long cus = n_cus, per_cu = 16 / NG, slots = cus * per_cu;   // 16 waves per CU at 128 VGPRs; a block is NG waves
     const long cols = (long)bx * n_pairs;
     double best = 1e30; int best_ty = nvalid < 128 ? (nvalid > 0 ? nvalid : 1) : 128;
     for (long m = 1; m <= 24; ++m) {
@@ -866,7 +867,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         // rows per block: a block is 64*NG threads and two blocks fit a CU only up to NG = 8, so the grid is a few
         // hundred large blocks and its quantisation matters.  Minimise rounds x steps-per-block over band heights
         // that fill whole rounds of block slots (a round whose CUs hold a single block runs ~0.65 as long).
-        int TY = strip_band_rows(bx, n_pairs, nvalid, win, q.NG);
+        int TY = strip_band_rows(bx, n_pairs, nvalid, win, q.NG, ctx->cus);
         q.TY = TY;
         const int NSL = strip::NS + q.NG;
         int PR = 0, ROWW = 0;
@@ -962,6 +963,8 @@ int sadbm_create(int device, sadbm_ctx **out)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
     snprintf(c->last_kernel, sizeof(c->last_kernel), "none");
+    c->cus = 256;
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->cus = v; }
     *out = c;
     return SADBM_OK;
 }

@@ -75,6 +75,7 @@ const char *sadbm_last_hip_error(void);              /* thread-local text of the
  * file-scope globals, SAD.cpp:9-11, and is not re-entrant). */
 int  sadbm_create(int device, sadbm_ctx **out);
 void sadbm_destroy(sadbm_ctx *ctx);
+int  sadbm_ctx_device(const sadbm_ctx *ctx);            /* the device the context was created on, -1 for NULL */
 
 /* getDisparity(left, right) with explicit winSize / DSR (SAD.cpp:24, :9, :11).  Host buffers in, host
  * buffer out, synchronous.  Every byte of `out` (rows x cols of `left`) is written.  Uses a lazily

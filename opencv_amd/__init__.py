@@ -11,3 +11,4 @@ from .stereo import (  # noqa: F401
 )
 from .bands import band_ranges, band_input_rows  # noqa: F401
 from .multi import shard_pairs, scatter_band, disparity_row_bands  # noqa: F401
+from . import filters  # noqa: F401,E402  (GetgaussianKernel, filter2D, highpass, blend: SURVEY 8f f4)

@@ -1,0 +1,179 @@
+// filters.hip -- Gaussian low/high-pass path of the reference's filter programs on gfx950 (include/sadbm_filters.h).
+//
+// filter2d_u8_f64_kernel: one 16x16 tile of output pixels per 256-thread block.  The source tile with its
+// (krows-1) x (kcols-1) halo is staged once in LDS as bytes, border pixels resolved with BORDER_REFLECT_101 while
+// staging; the taps are wave-uniform and come through the scalar cache.  Every thread accumulates its pixel's
+// channels in float64, taps in row-major order, multiply and add rounded separately (FP contraction is switched
+// off for this file), so the sums equal the CPU definition bit for bit.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/sadbm_filters.h"
+
+// The sums must round after every multiply and every add, as the CPU definition does: no FMA contraction in this
+// file (HIP's __dmul_rn/__dadd_rn are header inlines compiled with contraction allowed, so plain operators under
+// this pragma are used instead).
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int TILE = 16;
+constexpr int MAXTAPS = 4096;
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+template <int CH>
+__global__ void __launch_bounds__(TILE * TILE) filter2d_u8_f64_kernel(const uint8_t *__restrict__ src, int64_t spitch, int rows, int cols,
+                                                                     const double *__restrict__ kern, int krows, int kcols,
+                                                                     uint8_t *__restrict__ dst, int64_t dpitch)
+{
+    extern __shared__ uint8_t tile[];                          // [(TILE+krows-1)][(TILE+kcols-1)*CH]
+    const int tw = TILE + kcols - 1, th = TILE + krows - 1, trow = tw * CH;
+    const int x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
+    const int ay = krows / 2, ax = kcols / 2;
+    for (int i = threadIdx.x; i < th * tw; i += TILE * TILE) {
+        const int ty = i / tw, tx = i - ty * tw;
+        const uint8_t *p = src + (int64_t)reflect101(y0 + ty - ay, rows) * spitch + (int64_t)reflect101(x0 + tx - ax, cols) * CH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) tile[ty * trow + tx * CH + c] = p[c];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % TILE, ly = threadIdx.x / TILE;
+    const int x = x0 + lx, y = y0 + ly;
+    double acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = 0.0;
+    for (int i = 0; i < krows; ++i) {
+        const uint8_t *t = tile + (ly + i) * trow + lx * CH;
+        for (int j = 0; j < kcols; ++j) {
+            const double k = kern[i * kcols + j];              // wave-uniform -> scalar load
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { const double prod = k * (double)t[j * CH + c]; acc[c] = acc[c] + prod; }
+        }
+    }
+    if (x < cols && y < rows) {
+        uint8_t *o = dst + (int64_t)y * dpitch + (int64_t)x * CH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const double r = rint(acc[c]);                     // cvRound: half to even
+            o[c] = (uint8_t)(r < 0.0 ? 0.0 : r > 255.0 ? 255.0 : r);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) highpass_kernel(const uint8_t *__restrict__ a, int64_t apitch, const uint8_t *__restrict__ low,
+                                                       int64_t lpitch, int rowbytes, int add, uint8_t *__restrict__ dst, int64_t dpitch)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= rowbytes) return;
+    int s = a[(int64_t)y * apitch + x] + add;
+    s = s > 255 ? 255 : s;
+    const int d = s - low[(int64_t)y * lpitch + x];
+    dst[(int64_t)y * dpitch + x] = (uint8_t)(d < 0 ? 0 : d);
+}
+
+__global__ void __launch_bounds__(256) blend_kernel(const uint8_t *__restrict__ m1, int64_t p1, const uint8_t *__restrict__ m2, int64_t p2,
+                                                    int rows, int cols, int ch, double alpha, uint8_t *__restrict__ dst, int64_t dp)
+{
+    const int xb = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (xb >= cols * ch) return;
+    const int x = xb / ch, k = xb - x * ch;
+    const uint8_t a = m1[(int64_t)y * p1 + xb];
+    uint8_t v = a;
+    if (k < 3 && y >= 1 && y < rows - 1 && x >= 1 && x < cols - 1) {
+        // hybrid_image.cpp:91: int temp = alpha*a + (1.0-alpha)*b  (double arithmetic, truncation toward zero)
+        const double pa = alpha * (double)a, pb = (1.0 - alpha) * (double)m2[(int64_t)y * p2 + xb];
+        int t = (int)(pa + pb);
+        v = (uint8_t)(t > 255 ? 255 : t < 0 ? 0 : t);
+    }
+    dst[(int64_t)y * dp + xb] = v;
+}
+
+struct TapBuf { double *d; int device; };
+thread_local TapBuf g_taps[16] = {};
+
+}  // namespace
+
+extern "C" {
+
+int sadbm_gaussian_kernel(int size, int sigma, double *out)
+{
+    if (!out) return SADBM_E_NULL;
+    if (size < 1 || sigma < 1 || (int64_t)size * size > MAXTAPS) return SADBM_E_PARAM;
+    const int center = size / 2;                               // gaus_filter.cpp:18
+    double sum = 0;
+    for (int i = 0; i < size; ++i)
+        for (int j = 0; j < size; ++j) {
+            // gaus_filter.cpp:26: all-int expression, the division truncates before exp()
+            const int q = -((i - center) * (i - center) + (j - center) * (j - center)) / (2 * sigma * sigma);
+            out[i * size + j] = exp((double)q);
+            sum += out[i * size + j];
+        }
+    for (int i = 0; i < size * size; ++i) out[i] /= sum;      // gaus_filter.cpp:36
+    return SADBM_OK;
+}
+
+int sadbm_filter2d_device(sadbm_ctx *ctx, const uint8_t *dSrc, int64_t src_pitch, int rows, int cols, int channels,
+                          const double *kernel, int krows, int kcols, uint8_t *dDst, int64_t dst_pitch, void *stream)
+{
+    if (!ctx || !kernel) return SADBM_E_NULL;
+    if (channels != 1 && channels != 3 && channels != 4) return SADBM_E_TYPE;
+    if (rows < 0 || cols < 0) return SADBM_E_SIZE;
+    if (krows < 1 || kcols < 1 || (int64_t)krows * kcols > MAXTAPS) return SADBM_E_PARAM;
+    if (rows == 0 || cols == 0) return SADBM_OK;
+    if (!dSrc || !dDst) return SADBM_E_NULL;
+    if (src_pitch < (int64_t)cols * channels || dst_pitch < (int64_t)cols * channels) return SADBM_E_SIZE;
+    const int dev = sadbm_ctx_device(ctx);
+    if (hipSetDevice(dev) != hipSuccess) return SADBM_E_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    // taps: a per-thread, per-device 32 KB device buffer, refilled on the call's stream
+    if (dev < 0 || dev >= 16) return SADBM_E_PARAM;
+    if (!g_taps[dev].d && hipMalloc((void **)&g_taps[dev].d, MAXTAPS * sizeof(double)) != hipSuccess) return SADBM_E_ALLOC;
+    if (hipMemcpyAsync(g_taps[dev].d, kernel, sizeof(double) * krows * kcols, hipMemcpyHostToDevice, st) != hipSuccess) return SADBM_E_HIP;
+    const size_t lds = (size_t)(TILE + krows - 1) * (TILE + kcols - 1) * channels;
+    if (lds > 64 * 1024) return SADBM_E_PARAM;
+    dim3 grid((cols + TILE - 1) / TILE, (rows + TILE - 1) / TILE);
+    if (channels == 1) hipLaunchKernelGGL(filter2d_u8_f64_kernel<1>, grid, dim3(TILE * TILE), lds, st, dSrc, src_pitch, rows, cols, g_taps[dev].d, krows, kcols, dDst, dst_pitch);
+    else if (channels == 3) hipLaunchKernelGGL(filter2d_u8_f64_kernel<3>, grid, dim3(TILE * TILE), lds, st, dSrc, src_pitch, rows, cols, g_taps[dev].d, krows, kcols, dDst, dst_pitch);
+    else hipLaunchKernelGGL(filter2d_u8_f64_kernel<4>, grid, dim3(TILE * TILE), lds, st, dSrc, src_pitch, rows, cols, g_taps[dev].d, krows, kcols, dDst, dst_pitch);
+    return hipGetLastError() == hipSuccess ? SADBM_OK : SADBM_E_HIP;
+}
+
+int sadbm_highpass_device(sadbm_ctx *ctx, const uint8_t *dSrc, int64_t src_pitch, const uint8_t *dLow, int64_t low_pitch, int rows,
+                          int rowbytes, int add, uint8_t *dDst, int64_t dst_pitch, void *stream)
+{
+    if (!ctx) return SADBM_E_NULL;
+    if (rows < 0 || rowbytes < 0 || rows > 65535) return SADBM_E_SIZE;
+    if (rows == 0 || rowbytes == 0) return SADBM_OK;
+    if (!dSrc || !dLow || !dDst) return SADBM_E_NULL;
+    if (src_pitch < rowbytes || low_pitch < rowbytes || dst_pitch < rowbytes) return SADBM_E_SIZE;
+    if (hipSetDevice(sadbm_ctx_device(ctx)) != hipSuccess) return SADBM_E_HIP;
+    hipLaunchKernelGGL(highpass_kernel, dim3((rowbytes + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream, dSrc, src_pitch, dLow,
+                       low_pitch, rowbytes, add, dDst, dst_pitch);
+    return hipGetLastError() == hipSuccess ? SADBM_OK : SADBM_E_HIP;
+}
+
+int sadbm_blend_device(sadbm_ctx *ctx, const uint8_t *dM1, int64_t pitch1, const uint8_t *dM2, int64_t pitch2, int rows, int cols,
+                       int channels, double alpha, uint8_t *dDst, int64_t dst_pitch, void *stream)
+{
+    if (!ctx) return SADBM_E_NULL;
+    if (channels < 3 || channels > 4) return SADBM_E_TYPE;
+    if (rows < 0 || cols < 0 || rows > 65535) return SADBM_E_SIZE;
+    if (rows == 0 || cols == 0) return SADBM_OK;
+    if (!dM1 || !dM2 || !dDst) return SADBM_E_NULL;
+    const int64_t rowb = (int64_t)cols * channels;
+    if (pitch1 < rowb || pitch2 < rowb || dst_pitch < rowb) return SADBM_E_SIZE;
+    if (hipSetDevice(sadbm_ctx_device(ctx)) != hipSuccess) return SADBM_E_HIP;
+    hipLaunchKernelGGL(blend_kernel, dim3((unsigned)((rowb + 255) / 256), rows), dim3(256), 0, (hipStream_t)stream, dM1, pitch1, dM2, pitch2,
+                       rows, cols, channels, alpha, dDst, dst_pitch);
+    return hipGetLastError() == hipSuccess ? SADBM_OK : SADBM_E_HIP;
+}
+
+}  // extern "C"

@@ -987,6 +987,8 @@ void sadbm_destroy(sadbm_ctx *c)
 
 const char *sadbm_last_kernel_name(const sadbm_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 
+int sadbm_ctx_device(const sadbm_ctx *ctx) { return ctx ? ctx->device : -1; }
+
 int sadbm_profile_begin(sadbm_ctx *ctx, int max_launches)
 {
     if (!ctx) return SADBM_E_NULL;

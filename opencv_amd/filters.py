@@ -1,0 +1,97 @@
+"""Gaussian low/high-pass path of the reference's filter programs (gaus_filter.cpp, hybrid_image.cpp) over the C ABI
+of include/sadbm_filters.h.  Names follow the reference: GetgaussianKernel, filter2D, addWeighted(src,1,low,-1,0)
+(here `highpass`), add(mat1, mat2, alpha) (here `blend`).  Inputs are torch CUDA uint8 tensors (H, W) or (H, W, C);
+there is no CPU fallback."""
+import ctypes
+
+import numpy as np
+
+from .stereo import SadbmError, _check, _ctx_for, load_library
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    L = load_library()
+    if not _bound:
+        vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+        L.sadbm_gaussian_kernel.argtypes = [i32, i32, vp]
+        L.sadbm_filter2d_device.argtypes = [vp, vp, i64, i32, i32, i32, vp, i32, i32, vp, i64, vp]
+        L.sadbm_highpass_device.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp]
+        L.sadbm_blend_device.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, dbl, vp, i64, vp]
+        L.sadbm_ctx_device.argtypes = [vp]
+        for n in ("sadbm_gaussian_kernel", "sadbm_filter2d_device", "sadbm_highpass_device", "sadbm_blend_device", "sadbm_ctx_device"):
+            getattr(L, n).restype = i32
+        _bound = True
+    return L
+
+
+def GetgaussianKernel(size, sigma):
+    """size x size float64 kernel of gaus_filter.cpp:15-40 (integer-divided exponent, normalised)."""
+    out = np.empty((int(size), int(size)), np.float64)
+    _check(_lib().sadbm_gaussian_kernel(int(size), int(sigma), out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+def _view(t):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.dim() in (2, 3)):
+        raise TypeError("expected a CUDA uint8 tensor (H, W) or (H, W, C)")
+    ch = 1 if t.dim() == 2 else t.shape[2]
+    if t.stride(-1) != 1 or (t.dim() == 3 and t.stride(1) != ch):
+        t = t.contiguous()
+    return t, t.data_ptr(), t.stride(0), t.shape[0], t.shape[1], ch
+
+
+def _stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def filter2D(src, kernel, out=None):
+    """cv::filter2D(src, dst, src.depth(), kernel) as defined in include/sadbm_filters.h."""
+    import torch
+    s, sp, spitch, rows, cols, ch = _view(src)
+    k = np.ascontiguousarray(kernel, dtype=np.float64)
+    if k.ndim != 2:
+        raise SadbmError(-4, "kernel must be 2-D")
+    if out is None:
+        out = torch.empty_like(s)
+    o, op, opitch, orows, ocols, och = _view(out)
+    if (orows, ocols, och) != (rows, cols, ch):
+        raise SadbmError(-3, "output shape differs from the source's")
+    ctx = _ctx_for(s.device.index or 0)
+    _check(_lib().sadbm_filter2d_device(ctx.handle, sp, spitch, rows, cols, ch, k.ctypes.data_as(ctypes.c_void_p), k.shape[0], k.shape[1],
+                                        op, opitch, _stream()))
+    return out
+
+
+def highpass(src, low, add=0, out=None):
+    """addWeighted(src, 1, low, -1, 0): saturate(saturate(src + add) - low)."""
+    import torch
+    s, sp, spitch, rows, cols, ch = _view(src)
+    l, lp, lpitch, lrows, lcols, lch = _view(low)
+    if (lrows, lcols, lch) != (rows, cols, ch):
+        raise SadbmError(-3, "shapes differ")
+    if out is None:
+        out = torch.empty_like(s)
+    o, op, opitch, _r, _c, _h = _view(out)
+    ctx = _ctx_for(s.device.index or 0)
+    _check(_lib().sadbm_highpass_device(ctx.handle, sp, spitch, lp, lpitch, rows, cols * ch, int(add), op, opitch, _stream()))
+    return out
+
+
+def blend(mat1, mat2, alpha, out=None):
+    """add(mat1, mat2, alpha) of hybrid_image.cpp:78-100."""
+    import torch
+    a, ap, apitch, rows, cols, ch = _view(mat1)
+    b, bp, bpitch, brows, bcols, bch = _view(mat2)
+    if (brows, bcols, bch) != (rows, cols, ch):
+        raise SadbmError(-3, "shapes differ")
+    if out is None:
+        out = torch.empty_like(a)
+    o, op, opitch, _r, _c, _h = _view(out)
+    ctx = _ctx_for(a.device.index or 0)
+    _check(_lib().sadbm_blend_device(ctx.handle, ap, apitch, bp, bpitch, rows, cols, ch, ctypes.c_double(alpha), op, opitch, _stream()))
+    return out

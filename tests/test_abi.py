@@ -13,9 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "sadbm.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(sadbm_[a-z_0-9]+)\s*\(", text)))
+    syms = set()
+    for h in ("sadbm.h", "sadbm_filters.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms |= set(re.findall(r"\b(sadbm_[a-z_0-9]+)\s*\(", text))
+    return sorted(syms)
 
 
 def test_library_exports_every_declared_symbol():

@@ -95,3 +95,14 @@ def test_strip_constant_identical_and_binary_ties():
     big = np.full((30, 400), 255, np.uint8)                    # largest costs: 16-bit halves must not overflow (16x16x255 = 65280)
     zero = np.zeros((30, 400), np.uint8)
     assert np.array_equal(oa.get_disparity_host(big, zero, 16, 128, oa.RAW_LOC | oa.KERNEL_STRIP), oracle.literal(big, zero, 16, 128, oracle.RAW_LOC))
+
+
+@pytest.mark.parametrize("win", list(range(4, 26)))
+def test_strip_every_window_instantiation(win):
+    """Every window the strip matcher is instantiated for (its geometry is constexpr per WIN), at 64 / 128 / 256 disparity blocks."""
+    L, R = noise_pair(900 + win, 57, 283, shift=7)
+    for D in (50, 97, 256):
+        ctx = oa.Context(0)
+        got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel() == "sad_strip_kernel<%d>" % win
+        assert np.array_equal(got, oracle.box(L, R, win, D, oracle.RAW_LOC)), (win, D)

@@ -148,3 +148,12 @@ def test_errors():
         oracle.literal(L, R, 0, 8)
     with pytest.raises(ValueError):
         oracle.literal(L, R, 3, 0)
+
+
+def test_product_side_generator_matches_oracle_generator():
+    """opencv_amd.synth.rds (what bench.py feeds the GPU) == the oracle's rds, including the SURVEY check values."""
+    from opencv_amd import synth
+    for args in ((1, 320, 240, 4, 20, 0), (1, 320, 240, 4, 20, 1), (1000, 1242, 375, 5, 60, 0), (7, 33, 17, 40, 50, 0), (2, 1920, 1080, 8, 40, 0)):
+        a, b = synth.rds(*args), oracle.rds(*args)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), args
+    assert int(synth.splitmix64_stream(1, 3)[2]) == 0xf893a2eefb32555e

@@ -5,12 +5,13 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-import opencv_amd as oa, oracle
+import opencv_amd as oa
+from opencv_amd import synth
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 for name, (W, H, win, D) in {"1080p_w9_d64": (1920, 1080, 9, 64), "1080p_w9_d128": (1920, 1080, 9, 128), "4k_w15_d128": (3840, 2160, 15, 128)}.items():
-    L, R = oracle.rds(3, W, H, 16, 96, 0)
-    exp = oracle.box(L[:64 + win], R[:64 + win], win, D)[:64]
+    L, R = synth.rds(3, W, H, 16, 96, 0)
+    exp = oa.get_disparity_host(L, R, win, D)[:64]          # correctness of the pipeline vs the oracle: tests/test_gpu_pipeline.py
     # synchronous host API (pageable buffers, one frame at a time)
     oa.get_disparity_host(L, R, win, D)
     t0 = time.perf_counter()

@@ -4,10 +4,11 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-import opencv_amd as oa, oracle
+import opencv_amd as oa
+from opencv_amd import synth
 
 W, H, pairs = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080, 4)
-L, R = oracle.rds(7, W, H, 8, 40, 0)
+L, R = synth.rds(7, W, H, 8, 40, 0)
 dL = torch.from_numpy(np.stack([L] * pairs)).cuda(); dR = torch.from_numpy(np.stack([R] * pairs)).cuda()
 dO = torch.empty((pairs, H, W), dtype=torch.uint8, device="cuda")
 ctx = oa.Context(0)

@@ -897,7 +897,10 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         strip_geometry(win, NSL, &PR, &ROWW);
         const size_t lds = (size_t)(4 * ROWW + 3 * 64 * PR + 2 * 4 * 64) * 4;
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        dim3 g(bx, (nvalid + TY - 1) / TY, n_pairs);
+        q.nbx = bx; q.nby = (nvalid + TY - 1) / TY; q.npairs = n_pairs;
+        const long nblocks = (long)q.nbx * q.nby * q.npairs;
+        if (nblocks > 0x7ffffff0L) return SADBM_E_SIZE;
+        dim3 g((unsigned)((nblocks + 7) & ~7L));               // 1-D, XCD-aware order decoded in the kernel
         hipLaunchKernelGGL(sk, g, dim3(64 * q.NG), lds, st, q);
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_strip_kernel<%d>", win);
         HIPCHK(hipGetLastError());

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Register / spill table of the strip kernels: compiles sadbm.hip with -Rpass-analysis=kernel-resource-usage.
+   tools/regs.py [extra hipcc flags]"""
+import re, subprocess, sys, os
+src = os.path.join(os.path.dirname(__file__), "..", "opencv_amd", "csrc")
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-pthread", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage",
+       "-c", "-o", "/dev/null", "sadbm.hip"] + sys.argv[1:]
+out = subprocess.run(cmd, cwd=src, capture_output=True, text=True).stderr
+cur = None
+rows = {}
+for line in out.splitlines():
+    m = re.search(r"Function Name: (\S+)", line)
+    if m:
+        cur = m.group(1); rows[cur] = {}
+        continue
+    m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/lane\])?: (\d+)", line)
+    if m and cur:
+        rows[cur][m.group(1).strip()] = int(m.group(2))
+for name, r in rows.items():
+    m = re.search(r"sad_strip_kernelILi(\d+)ELi(\d+)E", name)
+    if not m:
+        continue
+    print(f"strip<{m.group(1)},{m.group(2)}> vgpr {r.get('VGPRs')} sgpr {r.get('SGPRs')} scratch {r.get('ScratchSize')} sgpr_spill {r.get('SGPRs Spill')} vgpr_spill {r.get('VGPRs Spill')} occ {r.get('Occupancy')}")

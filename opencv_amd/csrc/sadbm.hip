@@ -87,28 +87,35 @@ struct Params {
 //    One thread writes 16 aligned bytes of dst.
 // ---------------------------------------------------------------------------------------------
 typedef uint32_t prep_u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+// Plane z of dst holds FG frames side by side: frame f of the group at columns [PADL + f*Wp, PADL + f*Wp + cols), zeros
+// elsewhere (FG = 1: the plain padded plane of one frame).  Wp % 16 == 0 whenever FG > 1.
 __global__ void __launch_bounds__(256) prep_plane_kernel(const uint8_t *__restrict__ src, int64_t step, int64_t src_stride,
                                                           int ch, int rows, int cols, uint8_t *__restrict__ dst,
-                                                          int pitch, int64_t dst_stride)
+                                                          int pitch, int64_t dst_stride, int FG, int Wp, uint32_t Wp_magic, int n_pairs)
 {
     // one thread writes 16 aligned bytes of dst (pitch is a multiple of 128)
     const int wi = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
     if (wi * 16 >= pitch || y >= rows) return;
-    const uint8_t *s = src + (int64_t)blockIdx.z * src_stride + (int64_t)y * step;
-    const int xb = wi * 16 - PADL;
+    const int xv = wi * 16 - PADL;
+    int f = 0, xb = xv;
+    if (FG > 1 && xv >= 0) { f = (int)__umulhi((uint32_t)xv, Wp_magic); xb = xv - f * Wp; }   // xv / Wp: exact for xv, Wp < 65536
+    const int pair = blockIdx.z * FG + f;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (ch == 1 && xb >= 0 && xb + 16 <= cols) {
-        const prep_u32x4u q = *(const prep_u32x4u *)(s + xb);
-        v = make_uint4(q.x, q.y, q.z, q.w);
-    } else if (xb + 16 > 0 && xb < cols) {
-        uint32_t w[4] = {0, 0, 0, 0};
+    if (f < FG && pair < n_pairs) {
+        const uint8_t *s = src + (int64_t)pair * src_stride + (int64_t)y * step;
+        if (ch == 1 && xb >= 0 && xb + 16 <= cols) {
+            const prep_u32x4u q = *(const prep_u32x4u *)(s + xb);
+            v = make_uint4(q.x, q.y, q.z, q.w);
+        } else if (xb + 16 > 0 && xb < cols) {
+            uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            const int x = xb + b;
-            if (x >= 0 && x < cols) w[b >> 2] |= (uint32_t)s[(int64_t)x * ch] << (8 * (b & 3));
+            for (int b = 0; b < 16; ++b) {
+                const int x = xb + b;
+                if (x >= 0 && x < cols) w[b >> 2] |= (uint32_t)s[(int64_t)x * ch] << (8 * (b & 3));
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        v = make_uint4(w[0], w[1], w[2], w[3]);
     }
     *(uint4 *)(dst + (int64_t)blockIdx.z * dst_stride + (int64_t)y * pitch + wi * 16) = v;
 }
@@ -811,6 +818,25 @@ int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG, int n_cus)
     return best_ty;
 }
 
+// Frames per plane group for the strip matcher: fewest 256-column blocks over the batch, groups at most 16K columns
+// wide; one frame per plane unless grouping saves at least 1.5 % of the blocks.  Wp = frame pitch in columns (x16).
+void strip_frame_groups(int cols, int n_pairs, int *FG, int *Wp)
+{
+    *FG = 1; *Wp = cols;
+    const char *e = getenv("SADBM_STRIP_FG");
+    const int wp = (cols + 15) & ~15;
+    if (n_pairs < 2 || (e && atoi(e) == 1)) return;
+    auto blocks = [&](int fg) { return (long)((n_pairs + fg - 1) / fg) * (((long)(fg - 1) * wp + cols + 255) / 256); };
+    long best = blocks(1); int best_fg = 1;
+    const int fg_max = e && atoi(e) > 1 ? atoi(e) : 16384 / wp;
+    const int fg_cap = (65535 - cols) / wp + 1;               // plane columns stay below 65536 (prep_plane_kernel's division)
+    for (int fg = 2; fg <= fg_max && fg <= n_pairs && fg <= 1024 && fg <= fg_cap; ++fg) {
+        const long b = blocks(fg);
+        if (b < best) { best = b; best_fg = fg; }
+    }
+    if (best_fg > 1 && (double)best <= 0.985 * (double)blocks(1)) { *FG = best_fg; *Wp = wp; }
+}
+
 // Default matcher choice, from tools/sweep.py and bench.py on MI355X (profiles/r01h_sweep_*.txt): the strip matcher
 // needs >= 65 disparities to amortise its staged R words; above that it wins from single 640x480 frames (0.53-0.61x
 // the quad matcher's time) to batches of 4K frames (0.79-0.85x); the worst cases measured are mid-size batches with
@@ -847,20 +873,44 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     if (nvalid == 0) { snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "none"); return SADBM_OK; }
 
     const int need_rows = nvalid + win - 1;                   // <= rows_in (checked by callers)
-    const int pitch = (PADL + cols + PADR + 127) & ~127;
+
+    // matcher choice: SADBM_KERNEL_STRIP / SADBM_KERNEL_QUAD force one; env SADBM_MATCHER=strip|quad overrides the default
+    bool use_strip = false;
+    const int strip_ng = D <= 64 ? 4 : D <= 128 ? 8 : 16;    // disparity groups of 16 per block (multiple of 4)
+    strip_kernel_t sk = (win <= MAXWIN && cols < 65000) ? pick_strip_kernel(win, strip::NS + strip_ng, MakeSeq<MAXWIN>::type()) : nullptr;
+    if (sk && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL | SADBM_KERNEL_QUAD))) {
+        use_strip = (flags & SADBM_KERNEL_STRIP) != 0 || strip_is_default(win, D, cols, nvalid, n_pairs);
+        const char *e = getenv("SADBM_MATCHER");
+        if (e && !(flags & SADBM_KERNEL_STRIP)) use_strip = strcmp(e, "strip") == 0 ? true : (strcmp(e, "quad") == 0 ? false : use_strip);
+    }
+
+    // Scratch planes.  The quad / generic matchers get one padded plane pair per frame.  The strip matcher works on
+    // 256-column blocks, so frames whose width is not a multiple of 256 would leave the last block of every row part
+    // empty (1920: 6 %, 640: 19 %): it gets FG frames side by side in one plane, Wp columns apart, and treats the group
+    // as one wide frame whose strips know their frame (sad_strip.inc).
+    int FG = 1, Wp = cols;
+    if (use_strip) strip_frame_groups(cols, n_pairs, &FG, &Wp);
+    if (use_strip && ((size_t)(PADL + (size_t)(FG - 1) * Wp + cols + PADR + 127) & ~(size_t)127) * (size_t)need_rows > 0x7ff00000u) {
+        FG = 1; Wp = cols;                                    // the strip matcher addresses the R plane with 32-bit offsets
+        if ((size_t)((PADL + cols + PADR + 127) & ~127) * (size_t)need_rows > 0x7ff00000u) use_strip = false;
+    }
+    const int n_groups = (n_pairs + FG - 1) / FG;
+    const int vcols = (FG - 1) * Wp + cols;                    // columns of a group's plane that hold frames
+    const int pitch = (PADL + vcols + PADR + 127) & ~127;
     const size_t plane_bytes = (size_t)pitch * (size_t)need_rows;
-    // scratch layout: [pair][L plane | R plane], + slack: the strip matcher stages whole 256-column blocks
+    // scratch layout: [group][L plane | R plane], + slack: the strip matcher stages whole 256-column blocks
     // and may read a few hundred bytes past the last row (values only reach columns >= cols-win, which are 0)
-    int rc = grow(&ctx->planes, &ctx->planes_cap, 2 * plane_bytes * (size_t)n_pairs + 4096);
+    int rc = grow(&ctx->planes, &ctx->planes_cap, 2 * plane_bytes * (size_t)n_groups + 4096);
     if (rc) return rc;
     uint8_t *pL = ctx->planes, *pR = ctx->planes + plane_bytes;
 
     const bool prof = ctx->prof_on && ctx->ev_n < ctx->ev_cap;
     hipEvent_t *ev = prof ? ctx->ev + 3 * ctx->ev_n : nullptr;
     if (prof) HIPCHK(hipEventRecord(ev[0], st));
-    dim3 pg((pitch / 16 + 255) / 256, need_rows, n_pairs);
-    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dL, pitchL, pair_stride_in, channels, need_rows, cols, pL, pitch, (int64_t)(2 * plane_bytes));
-    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dR, pitchR, pair_stride_in, channels, need_rows, cols, pR, pitch, (int64_t)(2 * plane_bytes));
+    const uint32_t Wp_magic = (uint32_t)(0x100000000ull / (uint64_t)(Wp > 0 ? Wp : 1)) + 1u;
+    dim3 pg((pitch / 16 + 255) / 256, need_rows, n_groups);
+    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dL, pitchL, pair_stride_in, channels, need_rows, cols, pL, pitch, (int64_t)(2 * plane_bytes), FG, Wp, Wp_magic, n_pairs);
+    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dR, pitchR, pair_stride_in, channels, need_rows, cols, pR, pitch, (int64_t)(2 * plane_bytes), FG, Wp, Wp_magic, n_pairs);
     HIPCHK(hipGetLastError());
 
     Params p;
@@ -871,34 +921,26 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     p.NQ = 0; p.NCp = 0; p.TY = 0; p.LW = 0; p.RW = 0;
     if (prof) HIPCHK(hipEventRecord(ev[1], st));
 
-    // matcher choice: SADBM_KERNEL_STRIP / SADBM_KERNEL_QUAD force one; env SADBM_MATCHER=strip|quad overrides the default
-    bool use_strip = false;
-    const int strip_ng = D <= 64 ? 4 : D <= 128 ? 8 : 16;    // disparity groups of 16 per block (multiple of 4)
-    strip_kernel_t sk = (win <= MAXWIN) ? pick_strip_kernel(win, strip::NS + strip_ng, MakeSeq<MAXWIN>::type()) : nullptr;
-    if (sk && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL | SADBM_KERNEL_QUAD))) {
-        use_strip = (flags & SADBM_KERNEL_STRIP) != 0 || strip_is_default(win, D, cols, nvalid, n_pairs);
-        const char *e = getenv("SADBM_MATCHER");
-        if (e && !(flags & SADBM_KERNEL_STRIP)) use_strip = strcmp(e, "strip") == 0 ? true : (strcmp(e, "quad") == 0 ? false : use_strip);
-    }
     if (use_strip) {
         strip::SParams q;
         q.NG = strip_ng;
         q.Lrow0 = pL; q.pair_stride = (int64_t)(2 * plane_bytes); q.lr_delta = (uint32_t)plane_bytes;
         q.pitch = pitch; q.W = cols; q.nvalid = nvalid; q.win = win; q.D = D;
         q.out = dOut; q.out_pitch = out_pitch; q.out_stride = pair_stride_out; q.flags = flags; q.dword_store = p.dword_store;
-        const int bx = (cols + strip::XBW - 1) / strip::XBW;
+        const int bx = (vcols + strip::XBW - 1) / strip::XBW;
         // rows per block: a block is 64*NG threads and two blocks fit a CU only up to NG = 8, so the grid is a few
         // hundred large blocks and its quantisation matters.  Minimise rounds x steps-per-block over band heights
         // that fill whole rounds of block slots (a round whose CUs hold a single block runs ~0.65 as long).
-        int TY = strip_band_rows(bx, n_pairs, nvalid, win, q.NG, ctx->cus);
+        int TY = strip_band_rows(bx, n_groups, nvalid, win, q.NG, ctx->cus);
         q.TY = TY;
         const int NSL = strip::NS + q.NG;
         int PR = 0, ROWW = 0;
         strip_geometry(win, NSL, &PR, &ROWW);
-        const size_t lds = (size_t)(4 * ROWW + 3 * 64 * PR + 2 * 4 * 64) * 4;
+        const size_t lds = (size_t)(4 * ROWW + 3 * 64 * PR + 2 * 4 * 64 + 64) * 4;
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        q.nbx = bx; q.nby = (nvalid + TY - 1) / TY; q.npairs = n_pairs;
-        const long nblocks = (long)q.nbx * q.nby * q.npairs;
+        q.nbx = bx; q.nby = (nvalid + TY - 1) / TY; q.ngroups = n_groups;
+        q.FG = FG; q.Wp = Wp; q.npairs = n_pairs;
+        const long nblocks = (long)q.nbx * q.nby * q.ngroups;
         if (nblocks > 0x7ffffff0L) return SADBM_E_SIZE;
         dim3 g((unsigned)((nblocks + 7) & ~7L));               // 1-D, XCD-aware order decoded in the kernel
         hipLaunchKernelGGL(sk, g, dim3(64 * q.NG), lds, st, q);

@@ -284,10 +284,13 @@ def compute_batch_device(left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR,
     ctx = ctx or _ctx_for(dev)
     if out is None:
         out = torch.empty((n, rows, cols), dtype=torch.uint8, device=left.device)
+    elif (out.dtype != torch.uint8 or tuple(out.shape) != (n, rows, cols) or out.device != left.device
+          or (cols > 1 and out.stride(2) != 1)):
+        raise SadbmError(-3, "out must be an NxHxW uint8 tensor on the inputs' device with unit column stride")
     with torch.cuda.device(dev):
         _check(L.sadbm_compute_batch_device(ctx.handle, left.data_ptr(), right.data_ptr(), cols * ch, rows * cols * ch, n,
                                             rows, cols, ch, int(winSize), int(DSR), int(flags), out.data_ptr(),
-                                            cols, rows * cols, _stream_ptr(dev)))
+                                            out.stride(1), out.stride(0), _stream_ptr(dev)))   # pitched views allowed
     return out
 
 

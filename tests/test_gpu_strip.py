@@ -106,3 +106,38 @@ def test_strip_every_window_instantiation(win):
         got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
         assert ctx.last_kernel() == "sad_strip_kernel<%d>" % win
         assert np.array_equal(got, oracle.box(L, R, win, D, oracle.RAW_LOC)), (win, D)
+
+
+@pytest.mark.parametrize("shape,pairs", [((40, 203), 5), ((33, 640), 3), ((25, 100), 7), ((20, 16), 9), ((30, 250), 2), ((22, 1242), 4),
+                                         ((12, 37), 33)])
+def test_strip_frame_groups(shape, pairs, monkeypatch):
+    """Batches whose frame width is not a multiple of 256: the strip matcher lays several frames side by side in one
+    plane (run_pipeline / strip_frame_groups) -- every frame still equals the oracle, for widths that are not multiples
+    of 16, short last groups, BGR input, an unaligned output, a border-heavy D and one group per frame forced."""
+    import torch
+    H, W = shape
+    Ls, Rs = zip(*[noise_pair(31 * W + i, H, W, shift=3 + i % 5) for i in range(pairs)])
+    for win, D in ((7, 128), (9, 64), (15, 130), (21, 256)):
+        exp = [oracle.box(Ls[i], Rs[i], win, D) for i in range(pairs)]
+        for fg in (None, "1", "3"):
+            if fg is None:
+                monkeypatch.delenv("SADBM_STRIP_FG", raising=False)
+            else:
+                monkeypatch.setenv("SADBM_STRIP_FG", fg)
+            ctx = oa.Context(0)
+            out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
+            assert ctx.last_kernel() == ("sad_strip_kernel<%d>" % win if H > win and W > win else "none")
+            for i in range(pairs):
+                bad = np.argwhere(out[i] != exp[i])
+                assert bad.size == 0, (shape, pairs, win, D, fg, i, len(bad), bad[:6])
+    monkeypatch.delenv("SADBM_STRIP_FG", raising=False)
+    # BGR frames (plane 0) into an output batch whose rows are not 4-byte aligned
+    win, D = 9, 128
+    L3 = np.stack([np.stack([Ls[i], Rs[i], Ls[i]], -1) for i in range(pairs)])
+    R3 = np.stack([np.stack([Rs[i], Ls[i], Rs[i]], -1) for i in range(pairs)])
+    obuf = torch.full((pairs, H, W + 5), 7, dtype=torch.uint8, device="cuda")
+    oa.compute_batch_device(dev(L3), dev(R3), win, D, oa.KERNEL_STRIP, out=obuf[:, :, 1:1 + W])
+    got = obuf.cpu().numpy()
+    for i in range(pairs):
+        assert np.array_equal(got[i, :, 1:1 + W], oracle.box(Ls[i], Rs[i], win, D)), i
+    assert (got[:, :, 0] == 7).all() and (got[:, :, 1 + W:] == 7).all()

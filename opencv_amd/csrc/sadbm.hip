@@ -837,16 +837,15 @@ void strip_frame_groups(int cols, int n_pairs, int *FG, int *Wp)
     if (best_fg > 1 && (double)best <= 0.985 * (double)blocks(1)) { *FG = best_fg; *Wp = wp; }
 }
 
-// Default matcher choice, from tools/sweep.py and bench.py on MI355X (profiles/r01h_sweep_*.txt): the strip matcher
-// needs >= 65 disparities to amortise its staged R words; above that it wins from single 640x480 frames (0.53-0.61x
-// the quad matcher's time) to batches of 4K frames (0.79-0.85x); the worst cases measured are mid-size batches with
-// win = 3 mod 4 (1080p x 4: 1.02-1.08x).  At 64 disparities the two are within 10 % of each other; below ~48 the
-// quad matcher wins (strip 1.0-1.4x).
+// Default matcher choice, from tools/sweep.py on MI355X (profiles/r01h_sweep_*.txt, profiles/r01k_sweep_*.txt): the strip
+// matcher's blocks cover 64 disparities at least, so up to 32 disparities the quad matcher wins (strip 1.05-1.46x its
+// time).  From 33 on the strip matcher wins: batches 0.68-0.88x (D = 40..64) and 0.68-0.80x (D >= 100), single small
+// frames 0.43-0.97x; the worst cases measured are one 1080p frame at D = 40 (1.00-1.12x) and one 720p frame with
+// win >= 21 (1.01-1.10x).
 bool strip_is_default(int win, int D, int cols, int rows, int n_pairs)
 {
     (void)cols; (void)rows; (void)n_pairs;
-    if (win < 4) return false;
-    return D > 64 || (D > 48 && win >= 9);                     // 49..64 disparities: 0.89-1.00x for win >= 9, 1.04-1.07x for win = 7
+    return win >= 4 && D > 32;
 }
 
 // The whole device pipeline for n_pairs frames (or one band).  Input rows available: rows_in; output

@@ -842,10 +842,14 @@ void strip_frame_groups(int cols, int n_pairs, int *FG, int *Wp)
 // time).  From 33 on the strip matcher wins: batches 0.68-0.88x (D = 40..64) and 0.68-0.80x (D >= 100), single small
 // frames 0.43-0.97x; the worst cases measured are one 1080p frame at D = 40 (1.00-1.12x) and one 720p frame with
 // win >= 21 (1.01-1.10x).
+// Small jobs are latency bound and the strip matcher's blocks finish sooner: up to ~0.9 Mpixel per call it also wins at
+// D <= 32 (one 384x288 frame, win 7, D 30 -- the reference's own configuration: 19 us vs 35 us; 8 such frames 0.80x; one
+// 1280x720 frame 0.87-1.2x).
 bool strip_is_default(int win, int D, int cols, int rows, int n_pairs)
 {
-    (void)cols; (void)rows; (void)n_pairs;
-    return win >= 4 && D > 32;
+    if (win < 4) return false;
+    if (D > 32) return true;
+    return (long)n_pairs * rows * cols <= 700000L;
 }
 
 // The whole device pipeline for n_pairs frames (or one band).  Input rows available: rows_in; output

@@ -89,18 +89,24 @@ struct Params {
 typedef uint32_t prep_u32x4u __attribute__((ext_vector_type(4), aligned(1)));
 // Plane z of dst holds FG frames side by side: frame f of the group at columns [PADL + f*Wp, PADL + f*Wp + cols), zeros
 // elsewhere (FG = 1: the plain padded plane of one frame).  Wp % 16 == 0 whenever FG > 1.
-__global__ void __launch_bounds__(256) prep_plane_kernel(const uint8_t *__restrict__ src, int64_t step, int64_t src_stride,
-                                                          int ch, int rows, int cols, uint8_t *__restrict__ dst,
-                                                          int pitch, int64_t dst_stride, int FG, int Wp, uint32_t Wp_magic, int n_pairs)
+// blockIdx.z = 2 * group + (0: left image, 1: right image); dst planes are plane_bytes apart in that order.
+__global__ void __launch_bounds__(1024) prep_plane_kernel(const uint8_t *__restrict__ srcL, int64_t stepL,
+                                                           const uint8_t *__restrict__ srcR, int64_t stepR, int64_t src_stride,
+                                                           int ch, int rows, int cols, uint8_t *__restrict__ dst,
+                                                           int pitch, int64_t plane_bytes, int FG, int Wp, uint32_t Wp_magic, int n_pairs)
 {
+    const bool right = (blockIdx.z & 1) != 0;
+    const uint8_t *src = right ? srcR : srcL;
+    const int64_t step = right ? stepR : stepL;
+    const int group = blockIdx.z >> 1;
     // one thread writes 16 aligned bytes of dst (pitch is a multiple of 128)
-    const int wi = blockIdx.x * 256 + threadIdx.x;
+    const int wi = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (wi * 16 >= pitch || y >= rows) return;
     const int xv = wi * 16 - PADL;
     int f = 0, xb = xv;
     if (FG > 1 && xv >= 0) { f = (int)__umulhi((uint32_t)xv, Wp_magic); xb = xv - f * Wp; }   // xv / Wp: exact for xv, Wp < 65536
-    const int pair = blockIdx.z * FG + f;
+    const int pair = group * FG + f;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (f < FG && pair < n_pairs) {
         const uint8_t *s = src + (int64_t)pair * src_stride + (int64_t)y * step;
@@ -117,7 +123,7 @@ __global__ void __launch_bounds__(256) prep_plane_kernel(const uint8_t *__restri
             v = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
-    *(uint4 *)(dst + (int64_t)blockIdx.z * dst_stride + (int64_t)y * pitch + wi * 16) = v;
+    *(uint4 *)(dst + (int64_t)blockIdx.z * plane_bytes + (int64_t)y * pitch + wi * 16) = v;
 }
 
 // The zero frame of SAD.cpp:31,34: output rows [row0, row0+nrows) of every pair (any pitch / alignment).
@@ -911,9 +917,17 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     hipEvent_t *ev = prof ? ctx->ev + 3 * ctx->ev_n : nullptr;
     if (prof) HIPCHK(hipEventRecord(ev[0], st));
     const uint32_t Wp_magic = (uint32_t)(0x100000000ull / (uint64_t)(Wp > 0 ? Wp : 1)) + 1u;
-    dim3 pg((pitch / 16 + 255) / 256, need_rows, n_groups);
-    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dL, pitchL, pair_stride_in, channels, need_rows, cols, pL, pitch, (int64_t)(2 * plane_bytes), FG, Wp, Wp_magic, n_pairs);
-    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(256), 0, st, dR, pitchR, pair_stride_in, channels, need_rows, cols, pR, pitch, (int64_t)(2 * plane_bytes), FG, Wp, Wp_magic, n_pairs);
+    // block width: the multiple of 64 threads that wastes the fewest lanes over a row of pitch/16 chunks (4K: 264 chunks -> 320)
+    const int cpr = pitch / 16;
+    int pbx = 256; long pwaste = 1L << 60;
+    for (int b = 128; b <= 512; b += 64) {                     // measured (tools/dbg/prepbx.sh): 64-thread blocks are slow, ties -> larger
+        const long w = (long)((cpr + b - 1) / b) * b - cpr;
+        if (w <= pwaste) { pwaste = w; pbx = b; }
+    }
+    if (const char *e = getenv("SADBM_PREP_BX")) { if (atoi(e) >= 64 && atoi(e) <= 1024) pbx = atoi(e) & ~63; }
+    dim3 pg((cpr + pbx - 1) / pbx, need_rows, 2 * n_groups);   // n_groups <= 32767 (callers chunk)
+    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(pbx), 0, st, dL, pitchL, dR, pitchR, pair_stride_in, channels, need_rows, cols, pL, pitch,
+                       (int64_t)plane_bytes, FG, Wp, Wp_magic, n_pairs);
     HIPCHK(hipGetLastError());
 
     Params p;
@@ -1143,9 +1157,9 @@ int sadbm_compute_batch_device(sadbm_ctx *ctx, const uint8_t *dL, const uint8_t 
     int nvalid = rows - win;
     if (nvalid < 0 || cols - win <= 0) nvalid = 0;
     hipStream_t st = (hipStream_t)stream;   // NULL = the device's default stream, as in HIP
-    // grid.z carries the pair index (<= 65535 per launch)
-    for (int n0 = 0; n0 < n_pairs; n0 += 32768) {
-        int nn = n_pairs - n0 < 32768 ? n_pairs - n0 : 32768;
+    // grid.z carries the pair index, twice the group index in prep_plane_kernel (<= 65535 per launch)
+    for (int n0 = 0; n0 < n_pairs; n0 += 32767) {
+        int nn = n_pairs - n0 < 32767 ? n_pairs - n0 : 32767;
         rc = run_pipeline(ctx, dL + (int64_t)n0 * pair_stride_in, pitch_in, dR + (int64_t)n0 * pair_stride_in, pitch_in,
                           pair_stride_in, nn, rows, rows, nvalid, cols, channels, win, max_disp, flags,
                           dOut + (int64_t)n0 * pair_stride_out, out_pitch, pair_stride_out, st);

@@ -1,0 +1,46 @@
+"""Seeded random configurations of the batch entry point against the oracle: shapes around the strip (16), block (256)
+and plane-group boundaries, every matcher, raw / encoded output, 1/3/4 channels, pitched outputs.  Bit-exact bar."""
+import numpy as np
+import pytest
+import opencv_amd as oa
+import oracle
+from helpers import noise_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        win = int(rng.integers(1, 27))
+        D = int(rng.choice([1, 2, 15, 16, 17, 30, 31, 32, 33, 47, 48, 64, 65, 96, 100, 127, 128, 129, 200, 255, 256]))
+        H = int(rng.integers(1, 70))
+        W = int(rng.choice([int(rng.integers(1, 40)), int(rng.integers(40, 300)), int(rng.choice([255, 256, 257, 271, 272, 273, 511, 512, 513])),
+                            int(rng.integers(300, 700))]))
+        pairs = int(rng.choice([1, 1, 2, 3, 5, 8, 17]))
+        ch = int(rng.choice([1, 1, 3, 4]))
+        flags = int(rng.choice([0, oa.RAW_LOC])) | int(rng.choice([0, 0, oa.KERNEL_STRIP, oa.KERNEL_QUAD]))
+        pad = int(rng.choice([0, 0, 3, 16]))
+        out.append((win, D, H, W, pairs, ch, flags, pad))
+    return out
+
+
+@pytest.mark.parametrize("chunk", range(10))
+def test_random_batches_match_oracle(chunk):
+    import torch
+    for case, (win, D, H, W, pairs, ch, flags, pad) in enumerate(_cases(20, 1000 + chunk)):
+        Ls, Rs = zip(*[noise_pair(7 * case + i + 100 * chunk, H, W, shift=(1 + (i + case) % 9 if W > 12 else None), binary=(case % 4 == 3), ch=ch) for i in range(pairs)])
+        L, R = np.stack(Ls), np.stack(Rs)
+        obuf = torch.full((pairs, H, W + pad), 0xAB, dtype=torch.uint8, device="cuda")
+        out = obuf[:, :, pad // 2: pad // 2 + W] if pad else obuf
+        oa.compute_batch_device(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda(), win, D, flags, out=out)
+        got = obuf.cpu().numpy()
+        oflags = oracle.RAW_LOC if (flags & oa.RAW_LOC) else 0
+        for i in range(pairs):
+            exp = oracle.box(Ls[i], Rs[i], win, D, oflags)
+            g = got[i, :, pad // 2: pad // 2 + W]
+            bad = np.argwhere(g != exp)
+            assert bad.size == 0, ((win, D, H, W, pairs, ch, flags, pad), i, len(bad), bad[:5])
+        if pad:
+            assert (got[:, :, :pad // 2] == 0xAB).all() and (got[:, :, pad // 2 + W:] == 0xAB).all()

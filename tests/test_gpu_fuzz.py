@@ -44,3 +44,20 @@ def test_random_batches_match_oracle(chunk):
             assert bad.size == 0, ((win, D, H, W, pairs, ch, flags, pad), i, len(bad), bad[:5])
         if pad:
             assert (got[:, :, :pad // 2] == 0xAB).all() and (got[:, :, pad // 2 + W:] == 0xAB).all()
+
+
+def test_very_wide_frame_and_many_tiny_frames():
+    """Frames wider than the strip matcher's 16-bit column fields fall back to the quad matcher; hundreds of tiny frames
+    go into wide plane groups."""
+    import torch
+    L, R = noise_pair(5, 12, 66000, shift=7)
+    ctx = oa.Context(0)
+    got = oa.compute_device(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda(), 5, 40, 0, ctx=ctx).cpu().numpy()
+    assert ctx.last_kernel().startswith("sad_quad")
+    assert np.array_equal(got, oracle.box(L, R, 5, 40))
+    n = 700
+    Ls, Rs = zip(*[noise_pair(900 + i, 11, 23, shift=2) for i in range(n)])
+    out = oa.compute_batch_device(torch.from_numpy(np.stack(Ls)).cuda(), torch.from_numpy(np.stack(Rs)).cuda(), 4, 48, 0, ctx=ctx).cpu().numpy()
+    assert ctx.last_kernel() == "sad_strip_kernel<4>"
+    for i in range(n):
+        assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], 4, 48)), i

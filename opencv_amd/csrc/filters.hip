@@ -1,6 +1,6 @@
 // filters.hip -- Gaussian low/high-pass path of the reference's filter programs on gfx950 (include/sadbm_filters.h).
 //
-// filter2d_u8_f64_kernel: one 16x16 tile of output pixels per 256-thread block.  The source tile with its
+// filter2d_u8_f64_kernel: one 64x16 tile of output pixels per 256-thread block (4 pixels per thread).  The source tile with its
 // (krows-1) x (kcols-1) halo is staged once in LDS as bytes, border pixels resolved with BORDER_REFLECT_101 while
 // staging; the taps are wave-uniform and come through the scalar cache.  Every thread accumulates its pixel's
 // channels in float64, taps in row-major order, multiply and add rounded separately (FP contraction is switched
@@ -29,14 +29,18 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
-template <int CH>
+// Thread = PX horizontally adjacent output pixels x CH channels; block = 16 x 16 threads = a (16*PX) x 16 pixel tile.
+// Per tap row the thread slides a PX-pixel register window along the row: one LDS byte read + one convert per channel
+// and tap feeds PX multiply-add pairs, so the kernel issues ~2.5 f64-rate instructions per tap, pixel and channel
+// (2 is the floor: the definition rounds the product and the sum separately).
+template <int CH, int PX>
 __global__ void __launch_bounds__(TILE * TILE) filter2d_u8_f64_kernel(const uint8_t *__restrict__ src, int64_t spitch, int rows, int cols,
                                                                      const double *__restrict__ kern, int krows, int kcols,
                                                                      uint8_t *__restrict__ dst, int64_t dpitch)
 {
-    extern __shared__ uint8_t tile[];                          // [(TILE+krows-1)][(TILE+kcols-1)*CH]
-    const int tw = TILE + kcols - 1, th = TILE + krows - 1, trow = tw * CH;
-    const int x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
+    extern __shared__ uint8_t tile[];                          // [(TILE+krows-1)][(TILE*PX+kcols-1)*CH]
+    const int tw = TILE * PX + kcols - 1, th = TILE + krows - 1, trow = tw * CH;
+    const int x0 = blockIdx.x * (TILE * PX), y0 = blockIdx.y * TILE;
     const int ay = krows / 2, ax = kcols / 2;
     for (int i = threadIdx.x; i < th * tw; i += TILE * TILE) {
         const int ty = i / tw, tx = i - ty * tw;
@@ -46,24 +50,53 @@ __global__ void __launch_bounds__(TILE * TILE) filter2d_u8_f64_kernel(const uint
     }
     __syncthreads();
     const int lx = threadIdx.x % TILE, ly = threadIdx.x / TILE;
-    const int x = x0 + lx, y = y0 + ly;
-    double acc[CH];
+    const int x = x0 + lx * PX, y = y0 + ly;
+    double acc[PX][CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) acc[c] = 0.0;
+    for (int q = 0; q < PX; ++q)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[q][c] = 0.0;
+    const int jfull = kcols - kcols % PX;
     for (int i = 0; i < krows; ++i) {
-        const uint8_t *t = tile + (ly + i) * trow + lx * CH;
-        for (int j = 0; j < kcols; ++j) {
-            const double k = kern[i * kcols + j];              // wave-uniform -> scalar load
+        const uint8_t *t = tile + (ly + i) * trow + lx * (PX * CH);
+        const double *krow = kern + i * kcols;                 // wave-uniform -> scalar loads
+        // win[(j + q) % PX] holds pixel j + q of the row while tap j is applied
+        double win[PX][CH];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) { const double prod = k * (double)t[j * CH + c]; acc[c] = acc[c] + prod; }
+        for (int q = 0; q < PX - 1; ++q)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) win[q][c] = (double)t[q * CH + c];
+        for (int j0 = 0; j0 < jfull; j0 += PX) {
+#pragma unroll
+            for (int jj = 0; jj < PX; ++jj) {
+                const int j = j0 + jj;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) win[(jj + PX - 1) % PX][c] = (double)t[(j + PX - 1) * CH + c];
+                const double k = krow[j];
+#pragma unroll
+                for (int q = 0; q < PX; ++q)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) { const double prod = k * win[(jj + q) % PX][c]; acc[q][c] = acc[q][c] + prod; }
+            }
+        }
+        for (int j = jfull; j < kcols; ++j) {                  // kcols % PX trailing taps: straight from LDS
+            const double k = krow[j];
+#pragma unroll
+            for (int q = 0; q < PX; ++q)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) { const double prod = k * (double)t[(j + q) * CH + c]; acc[q][c] = acc[q][c] + prod; }
         }
     }
-    if (x < cols && y < rows) {
-        uint8_t *o = dst + (int64_t)y * dpitch + (int64_t)x * CH;
+    if (y < rows) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const double r = rint(acc[c]);                     // cvRound: half to even
-            o[c] = (uint8_t)(r < 0.0 ? 0.0 : r > 255.0 ? 255.0 : r);
+        for (int q = 0; q < PX; ++q) {
+            if (x + q >= cols) break;
+            uint8_t *o = dst + (int64_t)y * dpitch + (int64_t)(x + q) * CH;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const double r = rint(acc[q][c]);              // cvRound: half to even
+                o[c] = (uint8_t)(r < 0.0 ? 0.0 : r > 255.0 ? 255.0 : r);
+            }
         }
     }
 }
@@ -137,12 +170,23 @@ int sadbm_filter2d_device(sadbm_ctx *ctx, const uint8_t *dSrc, int64_t src_pitch
     if (dev < 0 || dev >= 16) return SADBM_E_PARAM;
     if (!g_taps[dev].d && hipMalloc((void **)&g_taps[dev].d, MAXTAPS * sizeof(double)) != hipSuccess) return SADBM_E_ALLOC;
     if (hipMemcpyAsync(g_taps[dev].d, kernel, sizeof(double) * krows * kcols, hipMemcpyHostToDevice, st) != hipSuccess) return SADBM_E_HIP;
-    const size_t lds = (size_t)(TILE + krows - 1) * (TILE + kcols - 1) * channels;
+    // pixels per thread: as many as still give every CU a few blocks (tools/filter_bench.py)
+    int px = 8;
+    auto nblocks = [&](int q) { return (long)((cols + TILE * q - 1) / (TILE * q)) * ((rows + TILE - 1) / TILE); };
+    auto ldsbytes = [&](int q) { return (size_t)(TILE + krows - 1) * (TILE * q + kcols - 1) * channels; };
+    while (px > 1 && (nblocks(px) < 512 || ldsbytes(px) > 64 * 1024)) px >>= 1;
+    if (const char *e = getenv("SADBM_FILTER_PX")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) px = v; }
+    const size_t lds = ldsbytes(px);
     if (lds > 64 * 1024) return SADBM_E_PARAM;
-    dim3 grid((cols + TILE - 1) / TILE, (rows + TILE - 1) / TILE);
-    if (channels == 1) hipLaunchKernelGGL(filter2d_u8_f64_kernel<1>, grid, dim3(TILE * TILE), lds, st, dSrc, src_pitch, rows, cols, g_taps[dev].d, krows, kcols, dDst, dst_pitch);
-    else if (channels == 3) hipLaunchKernelGGL(filter2d_u8_f64_kernel<3>, grid, dim3(TILE * TILE), lds, st, dSrc, src_pitch, rows, cols, g_taps[dev].d, krows, kcols, dDst, dst_pitch);
-    else hipLaunchKernelGGL(filter2d_u8_f64_kernel<4>, grid, dim3(TILE * TILE), lds, st, dSrc, src_pitch, rows, cols, g_taps[dev].d, krows, kcols, dDst, dst_pitch);
+    dim3 grid((cols + TILE * px - 1) / (TILE * px), (rows + TILE - 1) / TILE);
+#define SADBM_F2D(CH, PX) hipLaunchKernelGGL((filter2d_u8_f64_kernel<CH, PX>), grid, dim3(TILE * TILE), lds, st, dSrc, src_pitch, rows, cols, \
+                                             g_taps[dev].d, krows, kcols, dDst, dst_pitch)
+#define SADBM_F2D_PX(CH) do { if (px == 8) SADBM_F2D(CH, 8); else if (px == 4) SADBM_F2D(CH, 4); else if (px == 2) SADBM_F2D(CH, 2); else SADBM_F2D(CH, 1); } while (0)
+    if (channels == 1) SADBM_F2D_PX(1);
+    else if (channels == 3) SADBM_F2D_PX(3);
+    else SADBM_F2D_PX(4);
+#undef SADBM_F2D_PX
+#undef SADBM_F2D
     return hipGetLastError() == hipSuccess ? SADBM_OK : SADBM_E_HIP;
 }
 

@@ -5,6 +5,7 @@ import pytest
 
 import opencv_amd as oa
 import oracle
+from helpers import noise_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -50,3 +51,35 @@ def test_pipeline_zero_copy_inputs_bgr_and_busy():
     assert t == 2 and np.array_equal(pipe.wait(t), exp)
     with pytest.raises(oa.SadbmError):
         pipe.submit(L, R)                                   # channel count differs from the pipeline's
+
+
+@pytest.mark.gpu
+def test_host_api_is_reentrant_across_threads():
+    """the reference keeps its state in file-scope globals (SAD.cpp:9-11) and is not re-entrant; here every host
+    thread gets its own lazily created context, so concurrent getDisparity() calls with different parameters do not disturb
+    each other.  8 threads x 6 calls against the oracle."""
+    import threading
+    jobs = [(7, 30, (97, 211)), (9, 64, (120, 300)), (15, 128, (80, 517)), (5, 16, (60, 90)), (21, 200, (70, 400)), (4, 40, (33, 257)),
+            (11, 100, (64, 640)), (13, 48, (50, 129))]
+    data = []
+    for n, (win, D, (H, W)) in enumerate(jobs):
+        L, R = noise_pair(4000 + n, H, W, shift=3 + n)
+        data.append((win, D, L, R, oracle.box(L, R, win, D)))
+    errors = []
+
+    def worker(k):
+        try:
+            for rep in range(6):
+                win, D, L, R, exp = data[(k + rep) % len(data)]
+                got = oa.getDisparity(L, R, winSize=win, DSR=D)
+                if not np.array_equal(got, exp):
+                    errors.append((k, rep, win, D))
+        except Exception as e:      # noqa: BLE001 -- reported below
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -4,14 +4,18 @@
 // line-by-line semantics).  Written from scratch for CDNA4; nothing here is derived from the reference's
 // OpenCV-call-per-window structure.
 //
-// Pipeline per call (all on one stream):
-//   1. prep_plane_kernel  x2 : channel 0 of each input -> zero-padded single-channel plane in ctx scratch
-//                              (PADL bytes left, PADR right) so the matcher never needs bounds checks.
-//   2. sad_quad_kernel<WIN>  : the matcher (below).       [sad_generic_kernel for win > MAXWIN]
-//   3. hipMemset2DAsync      : the zero frame (rows >= rows-win), SAD.cpp:31,34.
+// Pipeline per call (all on one stream, run_pipeline below):
+//   1. zero_rows_kernel      : the zero frame (rows >= rows-win), SAD.cpp:31,34 -- one launch for the whole batch.
+//   2. prep_plane_kernel     : channel 0 of both inputs -> zero-padded single-channel planes in ctx scratch
+//                              (PADL bytes left, PADR right) so the matchers never need bounds checks; for batches on
+//                              the strip matcher several frames side by side per plane (strip_frame_groups).
+//   3. one matcher           : sad_strip_kernel<WIN,NSLM> (sad_strip.inc: 16 columns x 4 disparities per thread, operands
+//                              staged as ready-made dwords in LDS) from 33 disparities up and for small jobs;
+//                              sad_quad_lds_kernel<WIN,KC> (below) otherwise; sad_quad_kernel<WIN> = the same arithmetic
+//                              with operands through L1 (A/B flag); sad_generic_kernel for win > MAXWIN.
 //
-// The matcher (DESIGN.md "kernel S"):
-//   * one thread owns 4 adjacent output columns (a "quad", x0 = 4q) and a chunk of KC=16 consecutive
+// The quad matcher:
+//   * one thread owns 4 adjacent output columns (a "quad", x0 = 4q) and a chunk of KC = 8/16 consecutive
 //     disparities, and marches down a band of rows;
 //   * per row and disparity the four horizontal window sums are built from v_sad_u8 on 4-byte words:
 //     words that lie inside all four windows are summed once, the ragged ends use byte masks;
@@ -19,8 +23,7 @@
 //   * costs are accumulated in the high half of a 32-bit register whose low half holds the disparity,
 //     so v_min_u32 on the register IS the first-minimum argmin (cost<<16 | k);
 //   * chunks of one quad live in different threads of the block and are merged through LDS once per row.
-// There is no cross-lane traffic and no LDS in the inner loop; operands come through L1/L2 with
-// unaligned dword loads (the padded planes make x0-k addressable for every k).
+// DESIGN.md section 4 has the measurements behind each choice.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -38,12 +41,6 @@ constexpr int PADL = 320;     // >= 256 + 3 + slack; keeps every R read at x0-k-
 constexpr int PADR = 64;      // >= 4*NW + 8 for the widest window
 #ifndef SADBM_KC
 #define SADBM_KC 16
-#endif
-#ifndef SADBM_FUSED_STEP
-#define SADBM_FUSED_STEP 0
-#endif
-#ifndef SADBM_WPE_LDS
-#define SADBM_WPE_LDS 4
 #endif
 #ifndef SADBM_MERGE_ENDS
 #define SADBM_MERGE_ENDS 1
@@ -798,9 +795,6 @@ int check_params(int rows, int cols, int channels, int win, int max_disp, uint32
 
 int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-#ifndef SADBM_STRIP_MINBLOCKS
-#define SADBM_STRIP_MINBLOCKS 500
-#endif
 int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG, int n_cus)
 {
     const char *e = getenv("SADBM_STRIP_TY");

@@ -826,7 +826,8 @@ void strip_frame_groups(int cols, int n_pairs, int *FG, int *Wp)
     const char *e = getenv("SADBM_STRIP_FG");
     const int wp = (cols + 15) & ~15;
     if (n_pairs < 2 || (e && atoi(e) == 1)) return;
-    auto blocks = [&](int fg) { return (long)((n_pairs + fg - 1) / fg) * (((long)(fg - 1) * wp + cols + 255) / 256); };
+    auto width = [&](int nf) { return ((long)(nf - 1) * wp + cols + 255) / 256; };   // column blocks of a plane holding nf frames
+    auto blocks = [&](int fg) { return (long)(n_pairs / fg) * width(fg) + (n_pairs % fg ? width(n_pairs % fg) : 0); };
     long best = blocks(1); int best_fg = 1;
     const int fg_max = e && atoi(e) > 1 ? atoi(e) : 16384 / wp;
     const int fg_cap = (65535 - cols) / wp + 1;               // plane columns stay below 65536 (prep_plane_kernel's division)

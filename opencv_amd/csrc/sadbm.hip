@@ -864,17 +864,18 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     HIPCHK(hipSetDevice(ctx->device));
     if (nvalid < 0) nvalid = 0;
     if (cols - win <= 0) nvalid = 0;
-    // zero frame: rows [nvalid, rows_out) entirely (SAD.cpp:31,34); columns >= cols-win are written
-    // as zeros by the matcher itself.
-    if (nvalid < rows_out) {
+    // zero frame: rows [nvalid, rows_out) entirely (SAD.cpp:31,34); columns >= cols-win are written as zeros by the
+    // matchers themselves.  The strip matcher also writes these rows (blocks of its last band), unless there are many.
+    auto zero_rows = [&]() -> int {
         for (int z0 = nvalid; z0 < rows_out; z0 += 65535) {   // grid.y <= 65535
             const int zn = rows_out - z0 < 65535 ? rows_out - z0 : 65535;
             dim3 zg((cols + 1023) / 1024, zn, n_pairs);
             hipLaunchKernelGGL(zero_rows_kernel, zg, dim3(256), 0, st, dOut, out_pitch, pair_stride_out, z0, zn, cols);
         }
         HIPCHK(hipGetLastError());
-    }
-    if (nvalid == 0) { snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "none"); return SADBM_OK; }
+        return SADBM_OK;
+    };
+    if (nvalid == 0) { snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "none"); return zero_rows(); }
 
     const int need_rows = nvalid + win - 1;                   // <= rows_in (checked by callers)
 
@@ -898,6 +899,8 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         FG = 1; Wp = cols;                                    // the strip matcher addresses the R plane with 32-bit offsets
         if ((size_t)((PADL + cols + PADR + 127) & ~127) * (size_t)need_rows > 0x7ff00000u) use_strip = false;
     }
+    const bool strip_zeroes = use_strip && rows_out - nvalid <= 64;
+    if (nvalid < rows_out && !strip_zeroes) { int zrc = zero_rows(); if (zrc) return zrc; }
     const int n_groups = (n_pairs + FG - 1) / FG;
     const int vcols = (FG - 1) * Wp + cols;                    // columns of a group's plane that hold frames
     const int pitch = (PADL + vcols + PADR + 127) & ~127;
@@ -952,6 +955,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         q.nbx = bx; q.nby = (nvalid + TY - 1) / TY; q.ngroups = n_groups;
         q.FG = FG; q.Wp = Wp; q.npairs = n_pairs;
+        q.rows_out = strip_zeroes ? rows_out : nvalid;
         const long nblocks = (long)q.nbx * q.nby * q.ngroups;
         if (nblocks > 0x7ffffff0L) return SADBM_E_SIZE;
         dim3 g((unsigned)((nblocks + 7) & ~7L));               // 1-D, XCD-aware order decoded in the kernel

@@ -5,7 +5,8 @@
 // OpenCV-call-per-window structure.
 //
 // Pipeline per call (all on one stream, run_pipeline below):
-//   1. zero_rows_kernel      : the zero frame (rows >= rows-win), SAD.cpp:31,34 -- one launch for the whole batch.
+//   1. zero_rows_kernel      : the zero frame (rows >= rows-win), SAD.cpp:31,34 -- one launch for the whole batch
+//                              (not on the strip path: its last band of blocks writes those rows).
 //   2. prep_plane_kernel     : channel 0 of both inputs -> zero-padded single-channel planes in ctx scratch
 //                              (PADL bytes left, PADR right) so the matchers never need bounds checks; for batches on
 //                              the strip matcher several frames side by side per plane (strip_frame_groups).

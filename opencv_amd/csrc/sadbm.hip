@@ -85,6 +85,10 @@ struct Params {
 //    One thread writes 16 aligned bytes of dst.
 // ---------------------------------------------------------------------------------------------
 typedef uint32_t prep_u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+#ifndef SADBM_PREP_ROWS
+#define SADBM_PREP_ROWS 2
+#endif
+constexpr int PREP_ROWS = SADBM_PREP_ROWS;
 // Plane z of dst holds FG frames side by side: frame f of the group at columns [PADL + f*Wp, PADL + f*Wp + cols), zeros
 // elsewhere (FG = 1: the plain padded plane of one frame).  Wp % 16 == 0 whenever FG > 1.
 // blockIdx.z = 2 * group + (0: left image, 1: right image); dst planes are plane_bytes apart in that order.
@@ -97,31 +101,44 @@ __global__ void __launch_bounds__(1024) prep_plane_kernel(const uint8_t *__restr
     const uint8_t *src = right ? srcR : srcL;
     const int64_t step = right ? stepR : stepL;
     const int group = blockIdx.z >> 1;
-    // one thread writes 16 aligned bytes of dst (pitch is a multiple of 128)
+    // one thread writes 16 aligned bytes of PREP_ROWS consecutive rows of dst (pitch is a multiple of 128); the loads of
+    // all rows are issued before the first store
     const int wi = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (wi * 16 >= pitch || y >= rows) return;
+    const int y0 = blockIdx.y * PREP_ROWS;
+    if (wi * 16 >= pitch || y0 >= rows) return;
     const int xv = wi * 16 - PADL;
     int f = 0, xb = xv;
     if (FG > 1 && xv >= 0) { f = (int)__umulhi((uint32_t)xv, Wp_magic); xb = xv - f * Wp; }   // xv / Wp: exact for xv, Wp < 65536
     const int pair = group * FG + f;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (f < FG && pair < n_pairs) {
-        const uint8_t *s = src + (int64_t)pair * src_stride + (int64_t)y * step;
-        if (ch == 1 && xb >= 0 && xb + 16 <= cols) {
-            const prep_u32x4u q = *(const prep_u32x4u *)(s + xb);
-            v = make_uint4(q.x, q.y, q.z, q.w);
-        } else if (xb + 16 > 0 && xb < cols) {
-            uint32_t w[4] = {0, 0, 0, 0};
+    uint4 v[PREP_ROWS];
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const int x = xb + b;
-                if (x >= 0 && x < cols) w[b >> 2] |= (uint32_t)s[(int64_t)x * ch] << (8 * (b & 3));
+    for (int r = 0; r < PREP_ROWS; ++r) v[r] = make_uint4(0, 0, 0, 0);
+    if (f < FG && pair < n_pairs) {
+        const uint8_t *s0 = src + (int64_t)pair * src_stride + (int64_t)y0 * step;
+        if (ch == 1 && xb >= 0 && xb + 16 <= cols) {
+#pragma unroll
+            for (int r = 0; r < PREP_ROWS; ++r)
+                if (y0 + r < rows) {
+                    const prep_u32x4u q = *(const prep_u32x4u *)(s0 + (int64_t)r * step + xb);
+                    v[r] = make_uint4(q.x, q.y, q.z, q.w);
+                }
+        } else if (xb + 16 > 0 && xb < cols) {
+            for (int r = 0; r < PREP_ROWS && y0 + r < rows; ++r) {
+                const uint8_t *s = s0 + (int64_t)r * step;
+                uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int x = xb + b;
+                    if (x >= 0 && x < cols) w[b >> 2] |= (uint32_t)s[(int64_t)x * ch] << (8 * (b & 3));
+                }
+                v[r] = make_uint4(w[0], w[1], w[2], w[3]);
             }
-            v = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
-    *(uint4 *)(dst + (int64_t)blockIdx.z * plane_bytes + (int64_t)y * pitch + wi * 16) = v;
+    uint8_t *d = dst + (int64_t)blockIdx.z * plane_bytes + (int64_t)y0 * pitch + wi * 16;
+#pragma unroll
+    for (int r = 0; r < PREP_ROWS; ++r)
+        if (y0 + r < rows) *(uint4 *)(d + (int64_t)r * pitch) = v[r];
 }
 
 // The zero frame of SAD.cpp:31,34: output rows [row0, row0+nrows) of every pair (any pitch / alignment).
@@ -924,7 +941,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         if (w <= pwaste) { pwaste = w; pbx = b; }
     }
     if (const char *e = getenv("SADBM_PREP_BX")) { if (atoi(e) >= 64 && atoi(e) <= 1024) pbx = atoi(e) & ~63; }
-    dim3 pg((cpr + pbx - 1) / pbx, need_rows, 2 * n_groups);   // n_groups <= 32767 (callers chunk)
+    dim3 pg((cpr + pbx - 1) / pbx, (need_rows + PREP_ROWS - 1) / PREP_ROWS, 2 * n_groups);   // n_groups <= 32767 (callers chunk)
     hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(pbx), 0, st, dL, pitchL, dR, pitchR, pair_stride_in, channels, need_rows, cols, pL, pitch,
                        (int64_t)plane_bytes, FG, Wp, Wp_magic, n_pairs);
     HIPCHK(hipGetLastError());

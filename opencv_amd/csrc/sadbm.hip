@@ -74,6 +74,7 @@ struct Params {
     int NQ, NCp;              // quads per block, chunk slots per block (NQ*NCp = blockDim.x)
     int TY;                   // output rows per block
     int LW, RW;               // LDS row segment: L words, R words per shifted copy (sad_quad_lds_kernel)
+    int nbx, nby, npairs;     // sad_quad_lds_kernel: column blocks, row bands, pairs of its 1-D launch
     uint8_t *out;
     int64_t out_pitch, out_stride;
     uint32_t flags;
@@ -492,14 +493,20 @@ __global__ void __launch_bounds__(256, (KC == 16 ? (WIN <= 16 ? 4 : 3) : (WIN <=
     const int nthr = blockDim.x;
     const int q = tid & (p.NQ - 1);
     const int c = tid / p.NQ;
-    const int xb = blockIdx.x * p.NQ * 4;
+    // 1-D launch, XCD j walks the contiguous chunk j of the (column block, band, pair) order (as sad_strip_kernel: the
+    // left-border blocks take longer, and with 8 column blocks per row a 3-D grid would put them all on one XCD)
+    const int chunk = (int)(gridDim.x >> 3);
+    const int vb = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (vb >= p.nbx * p.nby * p.npairs) return;               // grid padded to a multiple of 8 (block-uniform exit)
+    const int bxi = vb % p.nbx, tb = vb / p.nbx, byi = tb % p.nby, pz = tb / p.nby;
+    const int xb = bxi * p.NQ * 4;
     const int x0 = xb + q * 4;
     const int k0 = c * KC;
-    const int yb = blockIdx.y * p.TY;
+    const int yb = byi * p.TY;
     const int ny = min(p.TY, p.nvalid - yb);
-    const uint8_t *L = p.L + (int64_t)blockIdx.z * p.plane_stride;
-    const uint8_t *R = p.R + (int64_t)blockIdx.z * p.plane_stride;
-    uint8_t *out = p.out + (int64_t)blockIdx.z * p.out_stride;
+    const uint8_t *L = p.L + (int64_t)pz * p.plane_stride;
+    const uint8_t *R = p.R + (int64_t)pz * p.plane_stride;
+    uint8_t *out = p.out + (int64_t)pz * p.out_stride;
     const int ocols = p.W - p.win;
     const int LW = p.LW, RW = p.RW, ROWW = LW + 4 * RW;
     uint4 *merge = reinterpret_cast<uint4 *>(smem + 4 * ROWW);   // [2][256], 16-byte aligned (4*ROWW words)
@@ -951,7 +958,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     p.W = cols; p.nvalid = nvalid; p.win = win; p.D = D;
     p.out = dOut; p.out_pitch = out_pitch; p.out_stride = pair_stride_out; p.flags = flags;
     p.dword_store = ((((uintptr_t)dOut) | (uintptr_t)out_pitch | (uintptr_t)pair_stride_out) & 3) == 0;
-    p.NQ = 0; p.NCp = 0; p.TY = 0; p.LW = 0; p.RW = 0;
+    p.NQ = 0; p.NCp = 0; p.TY = 0; p.LW = 0; p.RW = 0; p.nbx = p.nby = p.npairs = 0;
     if (prof) HIPCHK(hipEventRecord(ev[1], st));
 
     if (use_strip) {
@@ -1016,7 +1023,10 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
             p.RW = p.NQ + NW + p.NCp * KC / 4 + 1;
             const size_t lds = (size_t)(2 * 256 * 4 + 4 * (p.LW + 4 * p.RW)) * 4;
             quad_kernel_t k = pick_quad_lds_kernel(win, KC, MakeSeq<MAXWIN>::type());
-            hipLaunchKernelGGL(k, g, dim3(p.NQ * p.NCp), lds, st, p);
+            p.nbx = bx; p.nby = (nvalid + TY - 1) / TY; p.npairs = n_pairs;
+            const long nblocks = (long)p.nbx * p.nby * p.npairs;
+            if (nblocks > 0x7ffffff0L) return SADBM_E_SIZE;
+            hipLaunchKernelGGL(k, dim3((unsigned)((nblocks + 7) & ~7L)), dim3(p.NQ * p.NCp), lds, st, p);
             snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_quad_lds_kernel<%d,%d>", win, KC);
         }
     }

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""One-off parity soak on the GPU box: random large-ish batches (several column blocks, bands and plane groups) against the
+oracle.  tools/soak.py [cases] [seed]   -- prints one line per case, exits non-zero on the first mismatch."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import opencv_amd as oa
+import oracle
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time()
+for case in range(n):
+    win = int(rng.integers(4, 26))
+    D = int(rng.choice([16, 30, 33, 48, 64, 65, 100, 128, 129, 192, 255, 256]))
+    W = int(rng.choice([int(rng.integers(300, 1300)), int(rng.integers(1300, 4200)), 1920, 1242, 2048, 640]))
+    H = int(rng.integers(win + 2, 420))
+    pairs = int(rng.choice([1, 2, 3, 5, 9]))
+    flags = int(rng.choice([0, 0, oa.KERNEL_STRIP, oa.KERNEL_QUAD])) | int(rng.choice([0, oa.RAW_LOC]))
+    Ls, Rs = [], []
+    for i in range(pairs):
+        g = np.random.default_rng(1000 * case + i)
+        L = g.integers(0, 256, (H, W), dtype=np.uint8)
+        R = g.integers(0, 256, (H, W), dtype=np.uint8)
+        sh = int(g.integers(1, min(D, W // 2)))
+        R[:, :W - sh] = L[:, sh:]
+        if case % 5 == 4:
+            L = np.where(L & 0x80, 255, 0).astype(np.uint8); R = np.where(R & 0x80, 255, 0).astype(np.uint8)
+        Ls.append(L); Rs.append(R)
+    ctx = oa.Context(0)
+    out = oa.compute_batch_device(torch.from_numpy(np.stack(Ls)).cuda(), torch.from_numpy(np.stack(Rs)).cuda(), win, D, flags, ctx=ctx).cpu().numpy()
+    of = oracle.RAW_LOC if flags & oa.RAW_LOC else 0
+    for i in range(pairs):
+        exp = oracle.box(Ls[i], Rs[i], win, D, of)
+        if not np.array_equal(out[i], exp):
+            bad = np.argwhere(out[i] != exp)
+            print("MISMATCH", case, (win, D, W, H, pairs, flags), i, len(bad), bad[:5], flush=True)
+            sys.exit(1)
+    print("ok %3d win=%2d D=%3d %4dx%3d pairs=%d flags=%2d %s  t=%.0fs" % (case, win, D, W, H, pairs, flags, ctx.last_kernel(), time.time() - t0), flush=True)
+print("soak passed:", n, "cases")

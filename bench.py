@@ -23,11 +23,12 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (W, H, win, D, rds seed, d_bg, d_fg, pairs per step)
-    "cfg2_1080p_w9_d64": (1920, 1080, 9, 64, 2, 8, 40, 16),
-    "cfg2b_1080p_w9_d128": (1920, 1080, 9, 128, 2, 8, 40, 16),
-    "cfg3_4k_w15_d128": (3840, 2160, 15, 128, 3, 16, 96, 16),
+    # pairs per step: large enough that launch ramp and tail are amortised (scan in DESIGN.md section 7); cfg5 is BASELINE's 512
+    "cfg2_1080p_w9_d64": (1920, 1080, 9, 64, 2, 8, 40, 64),
+    "cfg2b_1080p_w9_d128": (1920, 1080, 9, 128, 2, 8, 40, 64),
+    "cfg3_4k_w15_d128": (3840, 2160, 15, 128, 3, 16, 96, 32),
     "cfg4_8k_w21_d256": (7680, 4320, 21, 256, 4, 32, 200, 4),
-    "cfg5_kitti_w7_d128": (1242, 375, 7, 128, 1000, 5, 60, 64),
+    "cfg5_kitti_w7_d128": (1242, 375, 7, 128, 1000, 5, 60, 512),
 }
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_NOMINAL_TOPS = 39.3         # 256 CU x 64 lanes x 2.4 GHz lane-ops/s (4-cycle wave64 issue)

@@ -12,7 +12,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
 for case in range(n):
-    win = int(rng.integers(4, 26))
+    win = int(rng.integers(4, 26)) if rng.random() < 0.85 else int(rng.choice([1, 2, 3, 26, 29, 31]))
     D = int(rng.choice([16, 30, 33, 48, 64, 65, 100, 128, 129, 192, 255, 256]))
     W = int(rng.choice([int(rng.integers(300, 1300)), int(rng.integers(1300, 4200)), 1920, 1242, 2048, 640]))
     H = int(rng.integers(win + 2, 420))

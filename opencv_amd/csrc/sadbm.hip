@@ -123,6 +123,18 @@ __global__ void __launch_bounds__(1024) prep_plane_kernel(const uint8_t *__restr
                     const prep_u32x4u q = *(const prep_u32x4u *)(s0 + (int64_t)r * step + xb);
                     v[r] = make_uint4(q.x, q.y, q.z, q.w);
                 }
+        } else if (ch == 1 && xb >= 0 && xb < cols && cols >= 16) {
+            // last, partial chunk of a row: the 16 bytes that END at the row's end, shifted down (never reads past the row)
+            const int sb = 8 * (16 - (cols - xb));            // 8 .. 120 bits
+#pragma unroll
+            for (int r = 0; r < PREP_ROWS; ++r)
+                if (y0 + r < rows) {
+                    const prep_u32x4u q = *(const prep_u32x4u *)(s0 + (int64_t)r * step + cols - 16);
+                    const uint64_t lo = (uint64_t)q.x | ((uint64_t)q.y << 32), hi = (uint64_t)q.z | ((uint64_t)q.w << 32);
+                    const uint64_t rlo = sb >= 64 ? hi >> (sb - 64) : (lo >> sb) | (hi << (64 - sb));
+                    const uint64_t rhi = sb >= 64 ? 0 : hi >> sb;
+                    v[r] = make_uint4((uint32_t)rlo, (uint32_t)(rlo >> 32), (uint32_t)rhi, (uint32_t)(rhi >> 32));
+                }
         } else if (xb + 16 > 0 && xb < cols) {
             for (int r = 0; r < PREP_ROWS && y0 + r < rows; ++r) {
                 const uint8_t *s = s0 + (int64_t)r * step;

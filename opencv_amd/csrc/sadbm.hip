@@ -123,6 +123,36 @@ __global__ void __launch_bounds__(1024) prep_plane_kernel(const uint8_t *__restr
                     const prep_u32x4u q = *(const prep_u32x4u *)(s0 + (int64_t)r * step + xb);
                     v[r] = make_uint4(q.x, q.y, q.z, q.w);
                 }
+        } else if (ch == 3 && xb >= 0 && xb + 16 <= cols) {
+            // BGR (what cv::imread hands the reference, SAD.cpp:65-66): 48 bytes in three 16-byte loads, every third byte kept
+#pragma unroll
+            for (int r = 0; r < PREP_ROWS; ++r)
+                if (y0 + r < rows) {
+                    const uint8_t *s = s0 + (int64_t)r * step + (int64_t)xb * 3;
+                    const prep_u32x4u a = *(const prep_u32x4u *)s, b = *(const prep_u32x4u *)(s + 16), c = *(const prep_u32x4u *)(s + 32);
+                    const uint32_t D[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+                    uint32_t w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t t = __builtin_amdgcn_perm(D[3 * j + 1], D[3 * j], 0x0C060300u);   // bytes 0, 3, 6 of the 12
+                        w[j] = __builtin_amdgcn_perm(D[3 * j + 2], t, 0x05020100u);                      // + byte 9
+                    }
+                    v[r] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+        } else if (ch == 4 && xb >= 0 && xb + 16 <= cols) {
+#pragma unroll
+            for (int r = 0; r < PREP_ROWS; ++r)
+                if (y0 + r < rows) {
+                    const uint8_t *s = s0 + (int64_t)r * step + (int64_t)xb * 4;
+                    uint32_t w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const prep_u32x4u q = *(const prep_u32x4u *)(s + 16 * j);
+                        const uint32_t t1 = __builtin_amdgcn_perm(q.y, q.x, 0x0C0C0400u), t2 = __builtin_amdgcn_perm(q.w, q.z, 0x0C0C0400u);
+                        w[j] = __builtin_amdgcn_perm(t2, t1, 0x05040100u);
+                    }
+                    v[r] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
         } else if (ch == 1 && xb >= 0 && xb < cols && cols >= 16) {
             // last, partial chunk of a row: the 16 bytes that END at the row's end, shifted down (never reads past the row)
             const int sb = 8 * (16 - (cols - xb));            // 8 .. 120 bits

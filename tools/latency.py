@@ -9,10 +9,11 @@ import opencv_amd as oa
 from opencv_amd import synth
 
 for name, (W, H, ch, win, D) in {"tsukuba-size 384x288 BGR w7 D30": (384, 288, 3, 7, 30), "1080p gray w9 D64": (1920, 1080, 1, 9, 64),
-                                 "4K gray w15 D128": (3840, 2160, 1, 15, 128)}.items():
+                                 "4K gray w15 D128": (3840, 2160, 1, 15, 128), "1080p BGR w9 D64": (1920, 1080, 3, 9, 64),
+                                 "4K BGR w15 D128": (3840, 2160, 3, 15, 128), "4K BGRA w15 D128": (3840, 2160, 4, 15, 128)}.items():
     L, R = synth.rds(5, W, H, 4, 20, 0)
-    if ch == 3:
-        L = np.ascontiguousarray(np.stack([L, L, L], -1)); R = np.ascontiguousarray(np.stack([R, R, R], -1))
+    if ch > 1:
+        L = np.ascontiguousarray(np.stack([L] * ch, -1)); R = np.ascontiguousarray(np.stack([R] * ch, -1))
     for _ in range(3):
         oa.get_disparity_host(L, R, win, D)
     n = 50

@@ -1,0 +1,68 @@
+// sadbm_internal.hpp -- declarations shared by the translation units of libsadbm.so (kernels are compiled in
+// separate files so they build in parallel): launch parameter blocks, padding constants, kernel pickers.
+#ifndef SADBM_INTERNAL_HPP
+#define SADBM_INTERNAL_HPP
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sadbm.h"
+
+namespace sadbm_detail {
+
+constexpr int PADL = 320;     // >= 256 + 3 + slack; keeps every R read at x0-k-3 >= -PADL addressable
+constexpr int PADR = 64;      // >= 4*NW + 8 for the widest window
+constexpr int MAXWIN = 25;    // widest window with a dedicated instantiation
+constexpr uint32_t KEY_MAX = 0xFFFFFFFFu;
+
+struct Params {
+    const uint8_t *L, *R;     // padded planes, pointing at column 0 of row 0
+    int64_t plane_stride;     // bytes between planes of consecutive pairs (batch)
+    int pitch;                // plane pitch
+    int W;                    // columns
+    int nvalid;               // output rows [0,nvalid) are computed (they need input rows < nvalid+win-1)
+    int win, D;
+    int NQ, NCp;              // quads per block, chunk slots per block (NQ*NCp = blockDim.x)
+    int TY;                   // output rows per block
+    int LW, RW;               // LDS row segment: L words, R words per shifted copy (sad_quad_lds_kernel)
+    int nbx, nby, npairs;     // sad_quad_lds_kernel: column blocks, row bands, pairs of its 1-D launch
+    uint8_t *out;
+    int64_t out_pitch, out_stride;
+    uint32_t flags;
+    int dword_store;          // out base and pitch 4-byte aligned
+};
+
+namespace strip {
+constexpr int NS = 16;                 // strips per block
+constexpr int XBW = NS * 16;           // output columns per block
+struct SParams {
+    const uint8_t *Lrow0;     // padded L plane of group 0, first byte of row 0 (column -PADL)
+    int64_t pair_stride;      // bytes between the L planes of consecutive groups
+    uint32_t lr_delta;        // R plane = L plane + lr_delta
+    int pitch, W, nvalid, win, D, TY, NG;
+    int nbx, nby, ngroups;    // column blocks, row bands, frame groups: the launch is 1-D over their product (padded to 8)
+    int FG, Wp, npairs;       // a group = FG frames side by side in one plane, Wp columns apart (Wp % 16 == 0); total frames
+    int rows_out;             // output rows [nvalid, rows_out) are zero-filled by the blocks of the last band
+    uint8_t *out;
+    int64_t out_pitch, out_stride;
+    uint32_t flags;
+    int dword_store;
+};
+}  // namespace strip
+
+typedef void (*quad_kernel_t)(Params);
+typedef void (*strip_kernel_t)(strip::SParams);
+
+// quad_kernels.hip
+quad_kernel_t pick_quad_kernel(int win);                 // sad_quad_kernel<win>, 1 <= win <= MAXWIN
+quad_kernel_t pick_quad_lds_kernel(int win, int kc);     // sad_quad_lds_kernel<win, kc>, kc in {8, 16}
+// strip_kernels.hip: nslm = NS + (4, 8 or 16 disparity groups); nullptr where the window has no strip instantiation
+strip_kernel_t pick_strip_kernel(int win, int nslm);
+// host copies of the strip kernel's compile-time geometry: staging passes per row image, dwords per row image
+void strip_geometry(int win, int nsl, int *pr, int *roww);
+
+template <int... I> struct Seq {};
+template <int N, int... I> struct MakeSeq : MakeSeq<N - 1, N - 1, I...> {};
+template <int... I> struct MakeSeq<0, I...> { typedef Seq<I...> type; };
+
+}  // namespace sadbm_detail
+#endif

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Register / spill table of the strip kernels: compiles sadbm.hip with -Rpass-analysis=kernel-resource-usage.
+"""Register / spill table of the strip kernels: compiles strip_kernels.hip with -Rpass-analysis=kernel-resource-usage.
    tools/regs.py [extra hipcc flags]"""
 import re, subprocess, sys, os
 src = os.path.join(os.path.dirname(__file__), "..", "opencv_amd", "csrc")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-pthread", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage",
-       "-c", "-o", "/dev/null", "sadbm.hip"] + sys.argv[1:]
-out = subprocess.run(cmd, cwd=src, capture_output=True, text=True).stderr
+       "-c", "-o", "/dev/null"]
+out = "".join(subprocess.run(cmd + ["-DSADBM_STRIP_PART_NG=%d" % n, "strip_kernels.hip"] + sys.argv[1:], cwd=src, capture_output=True, text=True).stderr for n in (4, 8, 16))
 cur = None
 rows = {}
 for line in out.splitlines():

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SADBM_VERSION 100
+#define SADBM_VERSION 200
 
 /* flags */
 #define SADBM_RAW_LOC        1u   /* write loc (0..max_disp-1) instead of (loc*16)&255; needs max_disp<=256 */
@@ -48,6 +48,9 @@ extern "C" {
 #define SADBM_E_HIP    -5   /* HIP runtime error (sadbm_last_hip_error() has the text) */
 #define SADBM_E_ALLOC  -6   /* device memory allocation failed */
 #define SADBM_E_BUSY   -7   /* pipeline slot still in flight (wait on its ticket first) / unknown ticket */
+#define SADBM_E_LIMIT  -8   /* sadbm_compute_device_static: the frame needs more scratch than the static buffer holds */
+#define SADBM_E_RCCL   -9   /* sadbm_multi_*: librccl could not be loaded, or an RCCL call failed
+                               (sadbm_last_hip_error() has the text) */
 
 /* Host-memory image view; maps 1:1 onto cv::Mat {data, rows, cols, channels(), step[0]} (CV_8U only).
  * Replaces the `Mat &left, Mat &right` arguments of getDisparity (SAD.cpp:24). */
@@ -64,7 +67,9 @@ typedef struct {
     int64_t step;
 } sadbm_plane;
 
-typedef struct sadbm_ctx sadbm_ctx;   /* per (host thread, device) state: scratch planes + a stream */
+typedef struct sadbm_ctx sadbm_ctx;   /* per (host thread, device, stream) state: scratch planes + a stream.  Calls on one
+                                         context are serialised; a call on another stream than the previous one first waits
+                                         for that one's work (the scratch is shared). */
 
 int         sadbm_version(void);
 const char *sadbm_strerror(int code);
@@ -82,6 +87,9 @@ int  sadbm_ctx_device(const sadbm_ctx *ctx);            /* the device the contex
  * created thread-local context on device 0. */
 int sadbm_get_disparity(const sadbm_image *left, const sadbm_image *right, int win, int max_disp,
                         uint32_t flags, sadbm_plane *out);
+
+/* Releases the calling thread's lazily created context now (it is also released when the thread exits). */
+void sadbm_thread_release(void);
 
 /* Same, on an explicit context (any device). */
 int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm_image *right,
@@ -131,12 +139,42 @@ int  sadbm_pipeline_submit(sadbm_pipeline *p, const sadbm_image *left, const sad
 int  sadbm_pipeline_wait(sadbm_pipeline *p, int64_t ticket, const uint8_t **result, int64_t *result_step,
                          sadbm_plane *out);
 
+/* Single-process multi-GPU (no reference counterpart: SAD.cpp is single-threaded).  A
+ * sadbm_multi owns, per GPU: a context, a stream, pinned and device staging and -- unless SADBM_MULTI_COPY_GATHER is
+ * given -- one rank of a single-process RCCL communicator (ncclCommInitAll; librccl is loaded at run time, so
+ * libsadbm.so itself does not link it).  `devices` may be NULL (= 0 .. ngpu-1).
+ *   sadbm_compute_multi       ONE frame split into ngpu row bands with a downward halo of win-1 rows (the window is
+ *                             anchored top-left, SAD.cpp:39); every GPU computes its band into its slot of its own copy
+ *                             of the full map and ONE all-gather of u8 bands (ncclAllGather, in place) leaves the full
+ *                             rows x cols map on every GPU.  sub_bands > 1 splits each band further and gathers the
+ *                             finished sub-band (grouped ncclBroadcast) while the next one is computed.  `out` (may be
+ *                             NULL) receives the map from the first GPU; sadbm_multi_device_map gives each GPU's copy.
+ *   sadbm_compute_multi_batch n_pairs independent pairs, pair n on GPU n % ngpu, no collective (batch data
+ *                             parallelism).
+ * SADBM_MULTI_COPY_GATHER: assemble the map with peer copies (hipMemcpyPeerAsync) instead of RCCL -- the same
+ * interface without the collective; it also allows one device to be listed several times (rehearsal of the
+ * partition on a single GPU). */
+#define SADBM_MULTI_COPY_GATHER 1u
+typedef struct sadbm_multi sadbm_multi;
+int  sadbm_multi_create(int ngpu, const int *devices, uint32_t multi_flags, sadbm_multi **out);
+void sadbm_multi_destroy(sadbm_multi *m);
+int  sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_image *right, int win, int max_disp,
+                         uint32_t flags, int sub_bands, sadbm_plane *out);
+int  sadbm_multi_device_map(sadbm_multi *m, int index, const uint8_t **dmap, int64_t *pitch);
+int  sadbm_compute_multi_batch(sadbm_multi *m, const sadbm_image *lefts, const sadbm_image *rights, int n_pairs, int win,
+                               int max_disp, uint32_t flags, sadbm_plane *outs);
+/* Row partition used by sadbm_compute_multi (pure host arithmetic): band `index` of `parts` covers output rows
+ * [*row0, *row1) and needs input rows [*row0, *in1); rows per band = ceil(rows / parts). */
+int  sadbm_band_plan(int rows, int parts, int win, int index, int *row0, int *row1, int *in1);
+
 /* Introspection for benchmarks (no reference counterpart): name of the matcher kernel the last call
  * on this ctx launched, and HIP-event timing of the matcher launches between profile_begin and
  * profile_end (events are recorded on the launch stream, nothing synchronises until profile_end). */
 const char *sadbm_last_kernel_name(const sadbm_ctx *ctx);
 int sadbm_profile_begin(sadbm_ctx *ctx, int max_launches);
 int sadbm_profile_end(sadbm_ctx *ctx, int *n_launches, float *matcher_ms_total, float *prep_ms_total);
+/* The tuning knobs of INTEGRATION.md are read from the environment once, at the first call; this re-reads them. */
+void sadbm_reload_env(void);
 
 #ifdef __cplusplus
 }

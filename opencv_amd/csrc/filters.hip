@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include "../../include/sadbm_filters.h"
+#include "sadbm_internal.hpp"
 
 // The sums must round after every multiply and every add, as the CPU definition does: no FMA contraction in this
 // file (HIP's __dmul_rn/__dadd_rn are header inlines compiled with contraction allowed, so plain operators under
@@ -129,9 +130,6 @@ __global__ void __launch_bounds__(256) blend_kernel(const uint8_t *__restrict__ 
     dst[(int64_t)y * dp + xb] = v;
 }
 
-struct TapBuf { double *d; int device; };
-thread_local TapBuf g_taps[16] = {};
-
 }  // namespace
 
 extern "C" {
@@ -166,21 +164,23 @@ int sadbm_filter2d_device(sadbm_ctx *ctx, const uint8_t *dSrc, int64_t src_pitch
     const int dev = sadbm_ctx_device(ctx);
     if (hipSetDevice(dev) != hipSuccess) return SADBM_E_HIP;
     hipStream_t st = (hipStream_t)stream;
-    // taps: a per-thread, per-device 32 KB device buffer, refilled on the call's stream
-    if (dev < 0 || dev >= 16) return SADBM_E_PARAM;
-    if (!g_taps[dev].d && hipMalloc((void **)&g_taps[dev].d, MAXTAPS * sizeof(double)) != hipSuccess) return SADBM_E_ALLOC;
-    if (hipMemcpyAsync(g_taps[dev].d, kernel, sizeof(double) * krows * kcols, hipMemcpyHostToDevice, st) != hipSuccess) return SADBM_E_HIP;
+    // taps: the context's 32 KB device buffer (one per context = one per stream, freed by sadbm_destroy), refilled on
+    // the call's stream -- a later call on the same stream overwrites it only after this call's kernel has run
+    double *dtaps = nullptr;
+    { const int trc = sadbm_ctx_taps(ctx, &dtaps, krows * kcols); if (trc) return trc; }
+    if (hipMemcpyAsync(dtaps, kernel, sizeof(double) * krows * kcols, hipMemcpyHostToDevice, st) != hipSuccess) return SADBM_E_HIP;
     // pixels per thread: as many as still give every CU a few blocks (tools/filter_bench.py)
     int px = 8;
     auto nblocks = [&](int q) { return (long)((cols + TILE * q - 1) / (TILE * q)) * ((rows + TILE - 1) / TILE); };
     auto ldsbytes = [&](int q) { return (size_t)(TILE + krows - 1) * (TILE * q + kcols - 1) * channels; };
     while (px > 1 && (nblocks(px) < 512 || ldsbytes(px) > 64 * 1024)) px >>= 1;
-    if (const char *e = getenv("SADBM_FILTER_PX")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) px = v; }
+    static const int px_env = [] { const char *e = getenv("SADBM_FILTER_PX"); return e ? atoi(e) : 0; }();   // read once
+    if (px_env == 1 || px_env == 2 || px_env == 4 || px_env == 8) px = px_env;
     const size_t lds = ldsbytes(px);
     if (lds > 64 * 1024) return SADBM_E_PARAM;
     dim3 grid((cols + TILE * px - 1) / (TILE * px), (rows + TILE - 1) / TILE);
 #define SADBM_F2D(CH, PX) hipLaunchKernelGGL((filter2d_u8_f64_kernel<CH, PX>), grid, dim3(TILE * TILE), lds, st, dSrc, src_pitch, rows, cols, \
-                                             g_taps[dev].d, krows, kcols, dDst, dst_pitch)
+                                             dtaps, krows, kcols, dDst, dst_pitch)
 #define SADBM_F2D_PX(CH) do { if (px == 8) SADBM_F2D(CH, 8); else if (px == 4) SADBM_F2D(CH, 4); else if (px == 2) SADBM_F2D(CH, 2); else SADBM_F2D(CH, 1); } while (0)
     if (channels == 1) SADBM_F2D_PX(1);
     else if (channels == 3) SADBM_F2D_PX(3);

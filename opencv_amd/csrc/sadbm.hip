@@ -23,6 +23,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -190,21 +191,29 @@ __global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
 // host side
 // ---------------------------------------------------------------------------------------------
 struct sadbm_ctx {
-    int device;
-    hipStream_t stream;          // owned
-    uint8_t *planes;             // scratch: L planes then R planes
-    size_t planes_cap;
-    uint8_t *stage_in;           // host API staging (device copies of the caller's host images)
-    size_t stage_in_cap;
-    uint8_t *stage_out;
-    size_t stage_out_cap;
-    uint8_t *pin_in, *pin_out;   // pinned host staging of the host API (pageable -> device copies are ~20x slower)
-    size_t pin_in_cap, pin_out_cap;
-    char last_kernel[64];
-    int cus;                     // compute units of the device (grid shaping)
+    int device = 0;
+    hipStream_t stream = nullptr;          // owned
+    uint8_t *planes = nullptr;             // scratch: L planes then R planes
+    size_t planes_cap = 0;
+    bool planes_fixed = false;             // planes is not ours to grow or free (sadbm_compute_device_static)
+    uint8_t *stage_in = nullptr;           // host API staging (device copies of the caller's host images)
+    size_t stage_in_cap = 0;
+    uint8_t *stage_out = nullptr;
+    size_t stage_out_cap = 0;
+    uint8_t *pin_in = nullptr, *pin_out = nullptr;   // pinned host staging of the host API (pageable -> device copies are ~20x slower)
+    size_t pin_in_cap = 0, pin_out_cap = 0;
+    double *taps = nullptr;                // filter taps of sadbm_filter2d_device (filters.hip), one buffer per context
+    char last_kernel[64] = "none";
+    int cus = 256;                         // compute units of the device (grid shaping)
+    // Calls on one context are serialised (mu) and ordered: the scratch planes are rewritten by every call, so when the
+    // caller's stream changes the new stream first waits for the work the previous one still holds (xev).
+    std::mutex mu;
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
+    hipEvent_t xev = nullptr;
     // profiling: event triples (before prep, before matcher, after matcher) per pipeline run
-    hipEvent_t *ev;
-    int ev_cap, ev_n, prof_on;
+    hipEvent_t *ev = nullptr;
+    int ev_cap = 0, ev_n = 0, prof_on = 0;
 };
 
 namespace {
@@ -270,10 +279,35 @@ int check_params(int rows, int cols, int channels, int win, int max_disp, uint32
 
 int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// Tuning / diagnostics knobs: the environment is read ONCE, at the first call; sadbm_reload_env()
+// re-reads it (tests and tools that flip a knob between calls).
+struct EnvKnobs {
+    int strip_ty = 0;            // SADBM_STRIP_TY   rows per block of the strip matcher (0 = model)
+    int strip_fg = 0;            // SADBM_STRIP_FG   frames per plane group (0 = choose, 1 = off, n = at most n)
+    int matcher = 0;             // SADBM_MATCHER    0 default, 1 strip, 2 quad
+    int prep_bx = 0;             // SADBM_PREP_BX    block width of prep_plane_kernel (0 = choose)
+    int kc = 0;                  // SADBM_KC         disparities per thread of the quad matcher (0 = choose)
+    long zc_bytes = 1 << 20;     // SADBM_ZEROCOPY_BYTES  host API: inputs up to this size are read by the GPU from pinned host memory
+};
+EnvKnobs read_env()
+{
+    EnvKnobs k;
+    auto geti = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    k.strip_ty = geti("SADBM_STRIP_TY", 0); if (k.strip_ty < 1) k.strip_ty = 0;
+    k.strip_fg = geti("SADBM_STRIP_FG", 0); if (k.strip_fg < 1) k.strip_fg = 0;
+    if (const char *e = getenv("SADBM_MATCHER")) k.matcher = strcmp(e, "strip") == 0 ? 1 : strcmp(e, "quad") == 0 ? 2 : 0;
+    k.prep_bx = geti("SADBM_PREP_BX", 0); if (k.prep_bx < 64 || k.prep_bx > 1024) k.prep_bx = 0; else k.prep_bx &= ~63;
+    k.kc = geti("SADBM_KC", 0); if (k.kc != 8 && k.kc != 16) k.kc = 0;
+    if (const char *e = getenv("SADBM_ZEROCOPY_BYTES")) k.zc_bytes = atol(e);
+    return k;
+}
+EnvKnobs g_env_store;
+std::once_flag g_env_once;
+const EnvKnobs &env() { std::call_once(g_env_once, [] { g_env_store = read_env(); }); return g_env_store; }
+
 int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG, int n_cus)
 {
-    const char *e = getenv("SADBM_STRIP_TY");
-    if (e && atoi(e) >= 1) return atoi(e);
+    if (env().strip_ty) return env().strip_ty;
     const long cus = n_cus, per_cu = 16 / NG, slots = cus * per_cu;   // 16 waves per CU at 128 VGPRs; a block is NG waves
     const long cols = (long)bx * n_pairs;
     double best = 1e30; int best_ty = nvalid < 128 ? (nvalid > 0 ? nvalid : 1) : 128;
@@ -298,13 +332,13 @@ int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG, int n_cus)
 void strip_frame_groups(int cols, int n_pairs, int *FG, int *Wp)
 {
     *FG = 1; *Wp = cols;
-    const char *e = getenv("SADBM_STRIP_FG");
+    const int efg = env().strip_fg;
     const int wp = (cols + 15) & ~15;
-    if (n_pairs < 2 || (e && atoi(e) == 1)) return;
+    if (n_pairs < 2 || efg == 1) return;
     auto width = [&](int nf) { return ((long)(nf - 1) * wp + cols + 255) / 256; };   // column blocks of a plane holding nf frames
     auto blocks = [&](int fg) { return (long)(n_pairs / fg) * width(fg) + (n_pairs % fg ? width(n_pairs % fg) : 0); };
     long best = blocks(1); int best_fg = 1;
-    const int fg_max = e && atoi(e) > 1 ? atoi(e) : 16384 / wp;
+    const int fg_max = efg > 1 ? efg : 16384 / wp;
     const int fg_cap = (65535 - cols) / wp + 1;               // plane columns stay below 65536 (prep_plane_kernel's division)
     for (int fg = 2; fg <= fg_max && fg <= n_pairs && fg <= 1024 && fg <= fg_cap; ++fg) {
         const long b = blocks(fg);
@@ -337,6 +371,15 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
 {
     if (n_pairs <= 0 || rows_out <= 0 || cols <= 0) return SADBM_OK;
     HIPCHK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> guard(ctx->mu);
+    // The scratch planes are rewritten by every call: work queued on another stream by the previous call must be done
+    // before this call's kernels touch them.  (If that stream has been destroyed meanwhile, wait for the whole device.)
+    if (ctx->has_last && ctx->last_stream != st) {
+        hipError_t e = ctx->xev ? hipEventRecord(ctx->xev, ctx->last_stream) : hipErrorInvalidHandle;
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->xev, 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }
+    }
+    ctx->last_stream = st; ctx->has_last = true;
     if (nvalid < 0) nvalid = 0;
     if (cols - win <= 0) nvalid = 0;
     // zero frame: rows [nvalid, rows_out) entirely (SAD.cpp:31,34); columns >= cols-win are written as zeros by the
@@ -360,8 +403,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     strip_kernel_t sk = (win <= MAXWIN && cols < 65000) ? pick_strip_kernel(win, strip::NS + strip_ng) : nullptr;
     if (sk && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL | SADBM_KERNEL_QUAD))) {
         use_strip = (flags & SADBM_KERNEL_STRIP) != 0 || strip_is_default(win, D, cols, nvalid, n_pairs);
-        const char *e = getenv("SADBM_MATCHER");
-        if (e && !(flags & SADBM_KERNEL_STRIP)) use_strip = strcmp(e, "strip") == 0 ? true : (strcmp(e, "quad") == 0 ? false : use_strip);
+        if (env().matcher && !(flags & SADBM_KERNEL_STRIP)) use_strip = env().matcher == 1;
     }
 
     // Scratch planes.  The quad / generic matchers get one padded plane pair per frame.  The strip matcher works on
@@ -382,7 +424,9 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     const size_t plane_bytes = (size_t)pitch * (size_t)need_rows;
     // scratch layout: [group][L plane | R plane], + slack: the strip matcher stages whole 256-column blocks
     // and may read a few hundred bytes past the last row (values only reach columns >= cols-win, which are 0)
-    int rc = grow(&ctx->planes, &ctx->planes_cap, 2 * plane_bytes * (size_t)n_groups + 4096);
+    const size_t planes_need = 2 * plane_bytes * (size_t)n_groups + 4096;
+    if (ctx->planes_fixed && planes_need > ctx->planes_cap) return SADBM_E_LIMIT;     // static scratch: never grown
+    int rc = ctx->planes_fixed ? SADBM_OK : grow(&ctx->planes, &ctx->planes_cap, planes_need);
     if (rc) return rc;
     uint8_t *pL = ctx->planes, *pR = ctx->planes + plane_bytes;
 
@@ -397,7 +441,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         const long w = (long)((cpr + b - 1) / b) * b - cpr;
         if (w <= pwaste) { pwaste = w; pbx = b; }
     }
-    if (const char *e = getenv("SADBM_PREP_BX")) { if (atoi(e) >= 64 && atoi(e) <= 1024) pbx = atoi(e) & ~63; }
+    if (env().prep_bx) pbx = env().prep_bx;
     dim3 pg((cpr + pbx - 1) / pbx, (need_rows + PREP_ROWS - 1) / PREP_ROWS, 2 * n_groups);   // n_groups <= 32767 (callers chunk)
     hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(pbx), 0, st, dL, pitchL, dR, pitchR, pair_stride_in, channels, need_rows, cols, pL, pitch,
                        (int64_t)plane_bytes, FG, Wp, Wp_magic, n_pairs);
@@ -450,7 +494,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         // disparities per thread: 16 keeps the per-row L work amortised for wide searches; 8 gives twice
         // the blocks and 5 waves/SIMD for D <= 64 (measured: cfg2 0.32 -> 0.25 ms, cfg3 0.78 vs 0.85 ms)
         int KC = use_global ? KCG : (D <= 64 ? 8 : 16);
-        if (!use_global) { const char *e = getenv("SADBM_KC"); if (e && (atoi(e) == 8 || atoi(e) == 16)) KC = atoi(e); }
+        if (!use_global && env().kc) KC = env().kc;
         const int NC = (D + KC - 1) / KC;                     // <= 256/KC
         p.NCp = pow2ceil(NC);
         const int quads = (cols + 3) / 4;
@@ -485,7 +529,14 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     return SADBM_OK;
 }
 
-thread_local sadbm_ctx *g_tls_ctx = nullptr;
+// The convenience call sadbm_get_disparity() keeps one context per host thread; it is released when the thread exits
+// (stream, device scratch, pinned staging -- about 25 MB per 4K pair).  Main-thread thread_locals are destroyed before
+// static-storage objects, i.e. while the HIP runtime is still alive.
+struct TlsCtx {
+    sadbm_ctx *c = nullptr;
+    ~TlsCtx() { if (c) { sadbm_ctx *d = c; c = nullptr; sadbm_destroy(d); } }
+};
+thread_local TlsCtx g_tls;
 
 }  // namespace
 
@@ -504,11 +555,14 @@ const char *sadbm_strerror(int code)
     case SADBM_E_HIP: return "HIP runtime error";
     case SADBM_E_ALLOC: return "device memory allocation failed";
     case SADBM_E_BUSY: return "pipeline slot still in flight, or ticket unknown";
+    case SADBM_E_LIMIT: return "input needs more scratch than the static buffer of sadbm_compute_device_static holds";
+    case SADBM_E_RCCL: return "RCCL error (sadbm_last_hip_error() has the text), or librccl could not be loaded";
     default: return "unknown error";
     }
 }
 
 const char *sadbm_last_hip_error(void) { return g_hip_err; }
+char *sadbm_internal_error_buffer(void) { return g_hip_err; }   // multi.hip writes its error text here (256 bytes)
 
 int sadbm_create(int device, sadbm_ctx **out)
 {
@@ -520,12 +574,10 @@ int sadbm_create(int device, sadbm_ctx **out)
     HIPCHK(hipSetDevice(device));
     sadbm_ctx *c = new (std::nothrow) sadbm_ctx();
     if (!c) return SADBM_E_ALLOC;
-    memset(c, 0, sizeof(*c));
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
-    snprintf(c->last_kernel, sizeof(c->last_kernel), "none");
-    c->cus = 256;
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->xev, hipEventDisableTiming);
+    if (e != hipSuccess) { if (c->stream) (void)hipStreamDestroy(c->stream); delete c; return hip_fail(e, "hipStreamCreate"); }
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->cus = v; }
     *out = c;
     return SADBM_OK;
@@ -535,16 +587,35 @@ void sadbm_destroy(sadbm_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    // the scratch may still be read by kernels the caller queued on its own stream: hipFree waits for the device
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    if (c->planes) (void)hipFree(c->planes);
+    if (c->planes && !c->planes_fixed) (void)hipFree(c->planes);
     if (c->stage_in) (void)hipFree(c->stage_in);
     if (c->stage_out) (void)hipFree(c->stage_out);
+    if (c->taps) (void)hipFree(c->taps);
     if (c->pin_in) (void)hipHostFree(c->pin_in);
     if (c->pin_out) (void)hipHostFree(c->pin_out);
+    if (c->xev) (void)hipEventDestroy(c->xev);
     for (int i = 0; i < 3 * c->ev_cap; ++i) (void)hipEventDestroy(c->ev[i]);
     delete[] c->ev;
-    if (g_tls_ctx == c) g_tls_ctx = nullptr;
+    if (g_tls.c == c) g_tls.c = nullptr;
     delete c;
+}
+
+void sadbm_reload_env(void) { (void)env(); g_env_store = read_env(); }
+
+int sadbm_ctx_taps(sadbm_ctx *ctx, double **taps, int count)
+{
+    if (!ctx || !taps) return SADBM_E_NULL;
+    if (count < 1 || count > 4096) return SADBM_E_PARAM;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> guard(ctx->mu);
+    if (!ctx->taps) {
+        hipError_t e = hipMalloc((void **)&ctx->taps, 4096 * sizeof(double));
+        if (e != hipSuccess) { ctx->taps = nullptr; hip_fail(e, "hipMalloc"); return SADBM_E_ALLOC; }
+    }
+    *taps = ctx->taps;
+    return SADBM_OK;
 }
 
 const char *sadbm_last_kernel_name(const sadbm_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
@@ -661,26 +732,40 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
     if (left->step < (int64_t)rowb || right->step < (int64_t)rowb || out->step < cols) return SADBM_E_SIZE;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t pin = (rowb + 255) & ~(size_t)255, pout = ((size_t)cols + 255) & ~(size_t)255;
-    rc = grow(&ctx->stage_in, &ctx->stage_in_cap, 2 * pin * rows);
+    const size_t in_bytes = 2 * pin * rows, out_bytes = pout * rows;
+    // Small frames (the reference's own 384x288 pair): the GPU reads the pinned staging buffer and writes the pinned
+    // result directly over PCIe -- three DMA set-ups (2 x H2D, 1 x D2H) cost more than the 0.8 MB they would move.
+    const bool zero_copy = (long)in_bytes <= env().zc_bytes;
+    rc = grow_pinned(&ctx->pin_in, &ctx->pin_in_cap, in_bytes);
     if (rc) return rc;
-    rc = grow(&ctx->stage_out, &ctx->stage_out_cap, pout * rows);
+    rc = grow_pinned(&ctx->pin_out, &ctx->pin_out_cap, out_bytes);
     if (rc) return rc;
-    rc = grow_pinned(&ctx->pin_in, &ctx->pin_in_cap, 2 * pin * rows);
-    if (rc) return rc;
-    rc = grow_pinned(&ctx->pin_out, &ctx->pin_out_cap, pout * rows);
-    if (rc) return rc;
-    uint8_t *dL = ctx->stage_in, *dR = ctx->stage_in + pin * rows;
     uint8_t *hL = ctx->pin_in, *hR = ctx->pin_in + pin * rows;
+    uint8_t *dL, *dR, *dO;
+    if (zero_copy) {
+        void *di = nullptr, *dout = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&di, ctx->pin_in, 0));
+        HIPCHK(hipHostGetDevicePointer(&dout, ctx->pin_out, 0));
+        dL = (uint8_t *)di; dR = dL + pin * rows; dO = (uint8_t *)dout;
+    } else {
+        rc = grow(&ctx->stage_in, &ctx->stage_in_cap, in_bytes);
+        if (rc) return rc;
+        rc = grow(&ctx->stage_out, &ctx->stage_out_cap, out_bytes);
+        if (rc) return rc;
+        dL = ctx->stage_in; dR = ctx->stage_in + pin * rows; dO = ctx->stage_out;
+    }
     hipStream_t st = ctx->stream;
-    // caller's (pageable, strided) rows -> pinned staging -> device; the R copy overlaps the L transfer
+    // caller's (pageable, strided) rows -> pinned staging (-> device: one copy for both images; frames of several MB
+    // are sent one by one so that the R rows are gathered while the L transfer runs)
+    const bool split = !zero_copy && in_bytes > ((size_t)8 << 20);
     copy_rows(hL, (int64_t)pin, left->data, left->step, rowb, rows);
-    HIPCHK(hipMemcpyAsync(dL, hL, pin * rows, hipMemcpyHostToDevice, st));
+    if (split) HIPCHK(hipMemcpyAsync(dL, hL, pin * rows, hipMemcpyHostToDevice, st));
     copy_rows(hR, (int64_t)pin, right->data, right->step, rowb, rows);
-    HIPCHK(hipMemcpyAsync(dR, hR, pin * rows, hipMemcpyHostToDevice, st));
-    rc = sadbm_compute_device(ctx, dL, (int64_t)pin, dR, (int64_t)pin, rows, cols, ch, win, max_disp, flags, ctx->stage_out,
-                              (int64_t)pout, st);
+    if (split) HIPCHK(hipMemcpyAsync(dR, hR, pin * rows, hipMemcpyHostToDevice, st));
+    else if (!zero_copy) HIPCHK(hipMemcpyAsync(dL, hL, in_bytes, hipMemcpyHostToDevice, st));
+    rc = sadbm_compute_device(ctx, dL, (int64_t)pin, dR, (int64_t)pin, rows, cols, ch, win, max_disp, flags, dO, (int64_t)pout, st);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->pin_out, ctx->stage_out, pout * rows, hipMemcpyDeviceToHost, st));
+    if (!zero_copy) HIPCHK(hipMemcpyAsync(ctx->pin_out, dO, out_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     copy_rows(out->data, out->step, ctx->pin_out, (int64_t)pout, (size_t)cols, rows);
     return SADBM_OK;
@@ -689,11 +774,16 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
 int sadbm_get_disparity(const sadbm_image *left, const sadbm_image *right, int win, int max_disp, uint32_t flags,
                         sadbm_plane *out)
 {
-    if (!g_tls_ctx) {
-        int rc = sadbm_create(0, &g_tls_ctx);
+    if (!g_tls.c) {
+        int rc = sadbm_create(0, &g_tls.c);
         if (rc) return rc;
     }
-    return sadbm_get_disparity_ctx(g_tls_ctx, left, right, win, max_disp, flags, out);
+    return sadbm_get_disparity_ctx(g_tls.c, left, right, win, max_disp, flags, out);
+}
+
+void sadbm_thread_release(void)
+{
+    if (g_tls.c) { sadbm_ctx *d = g_tls.c; g_tls.c = nullptr; sadbm_destroy(d); }
 }
 
 }  // extern "C"

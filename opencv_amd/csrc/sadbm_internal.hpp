@@ -7,6 +7,9 @@
 
 #include "../../include/sadbm.h"
 
+// the context's device buffer for filter taps (filters.hip), allocated on first use, freed by sadbm_destroy
+extern "C" int sadbm_ctx_taps(sadbm_ctx *ctx, double **taps, int count);
+
 namespace sadbm_detail {
 
 constexpr int PADL = 320;     // >= 256 + 3 + slack; keeps every R read at x0-k-3 >= -PADL addressable

@@ -34,64 +34,71 @@ def GetgaussianKernel(size, sigma):
     return out
 
 
-def _view(t):
+def _view(t, is_out=False):
     import torch
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.dim() in (2, 3)):
         raise TypeError("expected a CUDA uint8 tensor (H, W) or (H, W, C)")
     ch = 1 if t.dim() == 2 else t.shape[2]
     if t.stride(-1) != 1 or (t.dim() == 3 and t.stride(1) != ch):
+        if is_out:          # a copy would receive the result instead of the caller's tensor
+            raise SadbmError(-3, "out must have contiguous pixels (unit channel stride, pixel stride = channels)")
         t = t.contiguous()
     return t, t.data_ptr(), t.stride(0), t.shape[0], t.shape[1], ch
 
 
-def _stream():
+def _out_view(out, like, rows, cols, ch):
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if out is None:
+        out = torch.empty_like(like)
+    o, op, opitch, orows, ocols, och = _view(out, is_out=True)
+    if (orows, ocols, och) != (rows, cols, ch) or out.device != like.device:
+        raise SadbmError(-3, "out must have the source's shape and device")
+    return out, op, opitch
+
+
+def _launch(t):
+    """(context, stream pointer, device guard) for the device `t` lives on -- not the process-current device."""
+    import torch
+    dev = t.device.index or 0
+    st = torch.cuda.current_stream(dev).cuda_stream
+    return _ctx_for(dev, st), ctypes.c_void_p(st), torch.cuda.device(dev)
 
 
 def filter2D(src, kernel, out=None):
     """cv::filter2D(src, dst, src.depth(), kernel) as defined in include/sadbm_filters.h."""
-    import torch
     s, sp, spitch, rows, cols, ch = _view(src)
     k = np.ascontiguousarray(kernel, dtype=np.float64)
     if k.ndim != 2:
         raise SadbmError(-4, "kernel must be 2-D")
-    if out is None:
-        out = torch.empty_like(s)
-    o, op, opitch, orows, ocols, och = _view(out)
-    if (orows, ocols, och) != (rows, cols, ch):
-        raise SadbmError(-3, "output shape differs from the source's")
-    ctx = _ctx_for(s.device.index or 0)
-    _check(_lib().sadbm_filter2d_device(ctx.handle, sp, spitch, rows, cols, ch, k.ctypes.data_as(ctypes.c_void_p), k.shape[0], k.shape[1],
-                                        op, opitch, _stream()))
+    out, op, opitch = _out_view(out, s, rows, cols, ch)
+    ctx, st, guard = _launch(s)
+    with guard:
+        _check(_lib().sadbm_filter2d_device(ctx.handle, sp, spitch, rows, cols, ch, k.ctypes.data_as(ctypes.c_void_p), k.shape[0], k.shape[1],
+                                            op, opitch, st))
     return out
 
 
 def highpass(src, low, add=0, out=None):
     """addWeighted(src, 1, low, -1, 0): saturate(saturate(src + add) - low)."""
-    import torch
     s, sp, spitch, rows, cols, ch = _view(src)
     l, lp, lpitch, lrows, lcols, lch = _view(low)
-    if (lrows, lcols, lch) != (rows, cols, ch):
-        raise SadbmError(-3, "shapes differ")
-    if out is None:
-        out = torch.empty_like(s)
-    o, op, opitch, _r, _c, _h = _view(out)
-    ctx = _ctx_for(s.device.index or 0)
-    _check(_lib().sadbm_highpass_device(ctx.handle, sp, spitch, lp, lpitch, rows, cols * ch, int(add), op, opitch, _stream()))
+    if (lrows, lcols, lch) != (rows, cols, ch) or l.device != s.device:
+        raise SadbmError(-3, "shapes or devices differ")
+    out, op, opitch = _out_view(out, s, rows, cols, ch)
+    ctx, st, guard = _launch(s)
+    with guard:
+        _check(_lib().sadbm_highpass_device(ctx.handle, sp, spitch, lp, lpitch, rows, cols * ch, int(add), op, opitch, st))
     return out
 
 
 def blend(mat1, mat2, alpha, out=None):
     """add(mat1, mat2, alpha) of hybrid_image.cpp:78-100."""
-    import torch
     a, ap, apitch, rows, cols, ch = _view(mat1)
     b, bp, bpitch, brows, bcols, bch = _view(mat2)
-    if (brows, bcols, bch) != (rows, cols, ch):
-        raise SadbmError(-3, "shapes differ")
-    if out is None:
-        out = torch.empty_like(a)
-    o, op, opitch, _r, _c, _h = _view(out)
-    ctx = _ctx_for(a.device.index or 0)
-    _check(_lib().sadbm_blend_device(ctx.handle, ap, apitch, bp, bpitch, rows, cols, ch, ctypes.c_double(alpha), op, opitch, _stream()))
+    if (brows, bcols, bch) != (rows, cols, ch) or b.device != a.device:
+        raise SadbmError(-3, "shapes or devices differ")
+    out, op, opitch = _out_view(out, a, rows, cols, ch)
+    ctx, st, guard = _launch(a)
+    with guard:
+        _check(_lib().sadbm_blend_device(ctx.handle, ap, apitch, bp, bpitch, rows, cols, ch, ctypes.c_double(alpha), op, opitch, st))
     return out

@@ -6,9 +6,11 @@
 torch CUDA tensors (device-resident path) and returns the HxW uint8 disparity image.  torch is used
 only for device memory and streams; all arithmetic happens in the HIP kernels.
 """
+import collections
 import ctypes
 import os
 import subprocess
+import threading
 
 import numpy as np
 
@@ -93,6 +95,18 @@ def load_library():
     L.sadbm_pipeline_wait.argtypes = [vp, i64, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(_Plane)]
     for name in ("sadbm_pipeline_create", "sadbm_pipeline_inputs", "sadbm_pipeline_submit", "sadbm_pipeline_wait"):
         getattr(L, name).restype = i32
+    L.sadbm_multi_create.argtypes = [i32, ctypes.POINTER(i32), u32, ctypes.POINTER(vp)]
+    L.sadbm_multi_destroy.argtypes = [vp]
+    L.sadbm_multi_destroy.restype = None
+    L.sadbm_compute_multi.argtypes = [vp, ctypes.POINTER(_Image), ctypes.POINTER(_Image), i32, i32, u32, i32, ctypes.POINTER(_Plane)]
+    L.sadbm_multi_device_map.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    L.sadbm_compute_multi_batch.argtypes = [vp, ctypes.POINTER(_Image), ctypes.POINTER(_Image), i32, i32, i32, u32, ctypes.POINTER(_Plane)]
+    L.sadbm_band_plan.argtypes = [i32, i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.sadbm_reload_env.restype = None
+    L.sadbm_thread_release.restype = None
+    for name in ("sadbm_multi_create", "sadbm_compute_multi", "sadbm_multi_device_map",
+                 "sadbm_compute_multi_batch", "sadbm_band_plan"):
+        getattr(L, name).restype = i32
     for name in ("sadbm_profile_begin", "sadbm_profile_end", "sadbm_create", "sadbm_get_disparity", "sadbm_get_disparity_ctx", "sadbm_compute_device",
                  "sadbm_compute_band_device", "sadbm_compute_batch_device"):
         getattr(L, name).restype = i32
@@ -104,13 +118,14 @@ def _check(rc):
     if rc != 0:
         L = load_library()
         text = L.sadbm_strerror(rc).decode()
-        if rc == -5:
+        if rc in (-5, -9):
             text += " (" + L.sadbm_last_hip_error().decode() + ")"
         raise SadbmError(rc, text)
 
 
 class Context:
-    """One sadbm_ctx: device scratch + a stream.  One per (thread, device, stream)."""
+    """One sadbm_ctx: device scratch + a stream.  One per (thread, device, stream); the module-level functions keep
+    such a table themselves (_ctx_for) when no ctx is passed."""
 
     def __init__(self, device=0):
         L = load_library()
@@ -149,14 +164,39 @@ class Context:
         return load_library().sadbm_last_kernel_name(self._h).decode()
 
 
-_default_ctx = {}
+_default_ctx = threading.local()
+_DEFAULT_CTX_MAX = 8
 
 
-def _ctx_for(device):
-    c = _default_ctx.get(device)
+def _ctx_for(device, stream=None):
+    """The default context of the calling thread for (device, stream): a sadbm_ctx owns scratch planes that every
+    call rewrites, so threads and streams must not share one.  At most _DEFAULT_CTX_MAX per thread are kept (least
+    recently used first out; closing a context waits for the device)."""
+    if stream is None:
+        import torch
+        stream = torch.cuda.current_stream(device).cuda_stream
+    table = getattr(_default_ctx, "table", None)
+    if table is None:
+        table = _default_ctx.table = collections.OrderedDict()
+    key = (int(device), int(stream))
+    c = table.get(key)
     if c is None:
-        c = _default_ctx[device] = Context(device)
+        c = table[key] = Context(device)
+        while len(table) > _DEFAULT_CTX_MAX:
+            table.popitem(last=False)[1].close()
+    else:
+        table.move_to_end(key)
     return c
+
+
+def reload_env():
+    """Re-read the SADBM_* tuning knobs (the library reads the environment once, at its first call)."""
+    load_library().sadbm_reload_env()
+
+
+def thread_release():
+    """Release the calling thread's implicit context of the host API now (it also goes when the thread exits)."""
+    load_library().sadbm_thread_release()
 
 
 def _host_views(left, right):
@@ -367,3 +407,73 @@ class Pipeline:
         buf = (ctypes.c_uint8 * (step.value * self.rows)).from_address(ptr.value)
         a = np.frombuffer(buf, dtype=np.uint8).reshape(self.rows, step.value)[:, :self.cols]
         return a.copy() if copy else a
+
+
+MULTI_COPY_GATHER = 1
+
+
+def band_plan(rows, parts, win, index):
+    """(row0, row1, in1) of sadbm_band_plan: output rows [row0, row1), input rows [row0, in1)."""
+    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _check(load_library().sadbm_band_plan(int(rows), int(parts), int(win), int(index), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    return a.value, b.value, c.value
+
+
+def _img(a):
+    return _Image(a.ctypes.data, a.shape[0], a.shape[1], a.shape[2], a.strides[0] if a.shape[0] > 1 else max(a.shape[1] * a.shape[2], 1))
+
+
+class Multi:
+    """sadbm_multi: single-process multi-GPU (one frame as row bands + one RCCL all-gather, or a batch of pairs dealt
+    round-robin).  devices=None means 0..ngpu-1; multi_flags=MULTI_COPY_GATHER replaces RCCL by peer copies."""
+
+    def __init__(self, ngpu, devices=None, multi_flags=0):
+        L = load_library()
+        h = ctypes.c_void_p()
+        arr = (ctypes.c_int * ngpu)(*devices) if devices is not None else None
+        _check(L.sadbm_multi_create(int(ngpu), arr, int(multi_flags), ctypes.byref(h)))
+        self._h = h
+        self.ngpu = int(ngpu)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().sadbm_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def compute(self, left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags=0, sub_bands=1):
+        left, right = _host_views(left, right)
+        rows, cols, _ = left.shape
+        out = np.empty((rows, cols), dtype=np.uint8)
+        op = _Plane(out.ctypes.data, rows, cols, max(cols, 1))
+        li, ri = _img(left), _img(right)
+        _check(load_library().sadbm_compute_multi(self._h, ctypes.byref(li), ctypes.byref(ri), int(winSize), int(DSR), int(flags),
+                                                  int(sub_bands), ctypes.byref(op)))
+        return out
+
+    def device_map(self, index, rows, cols):
+        """Copy (torch uint8 tensor on that GPU) of GPU `index`'s full map of the last frame."""
+        import torch
+        ptr, pitch = ctypes.c_void_p(), ctypes.c_int64()
+        _check(load_library().sadbm_multi_device_map(self._h, int(index), ctypes.byref(ptr), ctypes.byref(pitch)))
+
+        class _Raw:                                             # raw device pointer -> torch via the CUDA array interface
+            __cuda_array_interface__ = {"shape": (rows, cols), "typestr": "|u1", "data": (ptr.value, False), "version": 2,
+                                        "strides": (pitch.value, 1)}
+        return torch.as_tensor(_Raw(), device="cuda").clone()
+
+    def compute_batch(self, lefts, rights, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags=0):
+        n = len(lefts)
+        views = [_host_views(l, r) for l, r in zip(lefts, rights)]
+        rows, cols, _ = views[0][0].shape
+        outs = [np.empty((rows, cols), dtype=np.uint8) for _ in range(n)]
+        li = (_Image * n)(*[_img(v[0]) for v in views])
+        ri = (_Image * n)(*[_img(v[1]) for v in views])
+        po = (_Plane * n)(*[_Plane(o.ctypes.data, rows, cols, max(cols, 1)) for o in outs])
+        _check(load_library().sadbm_compute_multi_batch(self._h, li, ri, n, int(winSize), int(DSR), int(flags), po))
+        return outs

@@ -15,3 +15,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _library_knobs_follow_the_environment():
+    """libsadbm reads its SADBM_* tuning knobs once; tests that flip one (monkeypatch.setenv + oa.reload_env()) get the
+    library re-synchronised with the restored environment afterwards (this fixture is set up before monkeypatch, so it
+    is torn down after it)."""
+    yield
+    import opencv_amd.stereo as st
+    if st._lib is not None:
+        st._lib.sadbm_reload_env()

@@ -28,13 +28,22 @@ def test_library_exports_every_declared_symbol():
             "sadbm_compute_batch_device", "sadbm_create", "sadbm_destroy"} <= set(syms)
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.sadbm_version() == 100
+    assert lib.sadbm_version() == 200
 
 
 def test_strerror_covers_codes():
     lib = oa.load_library()
-    texts = {lib.sadbm_strerror(c) for c in range(0, -8, -1)}
-    assert len(texts) == 8
+    texts = {lib.sadbm_strerror(c) for c in range(0, -10, -1)}
+    assert len(texts) == 10
+
+
+def test_multi_entry_points_validate_before_touching_a_device():
+    lib = oa.load_library()
+    assert lib.sadbm_compute_multi(None, None, None, 7, 30, 0, 1, None) == -1
+    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.sadbm_band_plan(10, 0, 7, 0, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == -4
+    h = ctypes.c_void_p()
+    assert lib.sadbm_multi_create(0, None, 0, ctypes.byref(h)) == -4
 
 
 def test_no_cpu_fallback_without_gpu():

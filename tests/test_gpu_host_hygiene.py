@@ -1,0 +1,125 @@
+"""Host-side behaviour of the C ABI on the GPU box: thread-local contexts are released, contexts tolerate stream
+changes and concurrent callers, the knobs are read once, small frames take the zero-copy path."""
+import threading
+
+import numpy as np
+import pytest
+
+import opencv_amd as oa
+import oracle
+from helpers import noise_pair, tsukuba_bgr
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_short_lived_threads_do_not_leak_device_memory():
+    """100 threads each call the thread-local host API once and exit: their contexts (stream, device scratch, pinned
+    staging) go with them."""
+    import torch
+    L, R = noise_pair(1, 120, 200, shift=3)
+    exp = oracle.box(L, R, 7, 30)
+    errs = []
+
+    def work():
+        try:
+            if not np.array_equal(oa.get_disparity_host(L, R, 7, 30), exp):
+                errs.append("mismatch")
+        except Exception as e:                                  # noqa: BLE001
+            errs.append(repr(e))
+
+    def burst(n):
+        for i in range(0, n, 10):
+            th = [threading.Thread(target=work) for _ in range(10)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+
+    burst(10)                                                  # warm-up: runtime pools settle
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    burst(100)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert not errs, errs[:3]
+    # a leaked context holds >= 0.3 MB of device memory (planes + staging); 100 of them would be >= 30 MB
+    assert free0 - free1 < 8 << 20, (free0, free1)
+
+
+def test_one_context_on_two_streams_and_two_threads():
+    """The advisor's case: device-path calls from two threads, each under its own torch stream.  The default context is
+    per (thread, device, stream); an explicitly shared context serialises and orders the calls itself."""
+    import torch
+    cases = [(noise_pair(10 + i, 300, 700, shift=4 + i), 9 + 2 * (i % 3), 64) for i in range(6)]
+    exps = [oracle.box(L, R, w, D) for (L, R), w, D in cases]
+    dl = [(dev(L), dev(R)) for (L, R), _, _ in cases]
+    shared = oa.Context(0)
+    for ctx in (None, shared):
+        results = [None] * len(cases)
+        errs = []
+
+        def run(ids):
+            try:
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    for _ in range(5):
+                        for i in ids:
+                            results[i] = oa.compute_device(dl[i][0], dl[i][1], cases[i][1], cases[i][2], ctx=ctx)
+                st.synchronize()
+            except Exception as e:                              # noqa: BLE001
+                errs.append(repr(e))
+
+        torch.cuda.synchronize()
+        th = [threading.Thread(target=run, args=(ids,)) for ids in ((0, 2, 4), (1, 3, 5))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        assert not errs, errs
+        for i, e in enumerate(exps):
+            assert np.array_equal(results[i].cpu().numpy(), e), (ctx is not None, i)
+    # one thread, one context, alternating streams
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(4):
+        for i in range(len(cases)):
+            with torch.cuda.stream(s1 if (i + rep) % 2 else s2):
+                outs.append((i, oa.compute_device(dl[i][0], dl[i][1], cases[i][1], cases[i][2], ctx=shared)))
+    torch.cuda.synchronize()
+    for i, o in outs:
+        assert np.array_equal(o.cpu().numpy(), exps[i]), i
+
+
+def test_knobs_are_read_once_until_reload(monkeypatch):
+    L, R = noise_pair(3, 70, 333, shift=9)
+    ctx = oa.Context(0)
+    oa.compute_device(dev(L), dev(R), 9, 64, oa.KERNEL_QUAD, ctx=ctx)
+    assert ctx.last_kernel() == "sad_quad_lds_kernel<9,8>"
+    monkeypatch.setenv("SADBM_KC", "16")
+    oa.compute_device(dev(L), dev(R), 9, 64, oa.KERNEL_QUAD, ctx=ctx)
+    assert ctx.last_kernel() == "sad_quad_lds_kernel<9,8>"       # not re-read per call
+    oa.reload_env()
+    oa.compute_device(dev(L), dev(R), 9, 64, oa.KERNEL_QUAD, ctx=ctx)
+    assert ctx.last_kernel() == "sad_quad_lds_kernel<9,16>"
+
+
+def test_host_api_zero_copy_and_staged_paths_agree(monkeypatch):
+    """Small frames are read from / written to pinned host memory by the GPU, larger ones go through device staging;
+    force each on the reference's own pair and on a pitched ROI."""
+    L, R = tsukuba_bgr()
+    exp = oracle.literal(np.ascontiguousarray(L[:, :, 0]), np.ascontiguousarray(R[:, :, 0]), 7, 30)
+    bl, br = noise_pair(23, 80, 160)
+    roi = (bl[10:70, 16:140], br[10:70, 16:140])
+    exp_roi = oracle.literal(np.ascontiguousarray(roi[0]), np.ascontiguousarray(roi[1]), 7, 30)
+    for zc in ("0", "100000000"):
+        monkeypatch.setenv("SADBM_ZEROCOPY_BYTES", zc)
+        oa.reload_env()
+        assert np.array_equal(oa.get_disparity_host(L, R, 7, 30), exp), zc
+        assert np.array_equal(oa.get_disparity_host(roi[0], roi[1], 7, 30), exp_roi), zc
+        oa.thread_release()                                    # next round starts from a fresh thread context

@@ -1,0 +1,55 @@
+"""sadbm_multi_* (single-process multi-GPU C ABI) on the one-GPU box: ngpu = 1 through RCCL (ncclCommInitAll of one
+rank, in-place ncclAllGather / grouped ncclBroadcast), and 2..8 "devices" that are all GPU 0 with the peer-copy gather
+behind the same interface (the partition and the exchange without a cluster)."""
+import numpy as np
+import pytest
+
+import opencv_amd as oa
+import oracle
+from helpers import noise_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("sub_bands", [1, 3])
+def test_multi_rccl_one_rank(sub_bands):
+    L, R = noise_pair(7, 211, 333, shift=6)
+    m = oa.Multi(1)
+    for win, D in ((15, 48), (7, 30), (21, 200)):
+        exp = oracle.box(L, R, win, D)
+        got = m.compute(L, R, win, D, sub_bands=sub_bands)
+        assert np.array_equal(got, exp), (win, D)
+        assert np.array_equal(m.device_map(0, *L.shape).cpu().numpy(), exp)
+    m.close()
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 8])
+@pytest.mark.parametrize("sub_bands", [1, 4])
+def test_multi_copy_gather_virtual_devices(n, sub_bands):
+    """H not divisible by n, bands shorter than the window, empty last bands, BGR input."""
+    m = oa.Multi(n, devices=[0] * n, multi_flags=oa.MULTI_COPY_GATHER)
+    for (H, W, ch) in ((97, 150, 1), (11, 90, 1), (64, 257, 3)):
+        L, R = noise_pair(H + n, H, W, shift=4, ch=ch)
+        for win, D in ((9, 40), (15, 128)):
+            exp = oracle.box(np.ascontiguousarray(L[..., 0]) if ch > 1 else L, np.ascontiguousarray(R[..., 0]) if ch > 1 else R, win, D)
+            got = m.compute(L, R, win, D, sub_bands=sub_bands)
+            assert np.array_equal(got, exp), (n, H, W, ch, win, D)
+            for i in range(n):                                  # every "GPU" ends with the full map
+                assert np.array_equal(m.device_map(i, H, W).cpu().numpy(), exp), i
+    m.close()
+
+
+@pytest.mark.parametrize("n,flags", [(1, 0), (3, oa.MULTI_COPY_GATHER)])
+def test_multi_batch_round_robin(n, flags):
+    m = oa.Multi(n, devices=[0] * n, multi_flags=flags)
+    pairs = [oracle.rds(1000 + i, 310, 95, 5 + i, 20 + i, 0) for i in range(7)]
+    outs = m.compute_batch([p[0] for p in pairs], [p[1] for p in pairs], 7, 64)
+    for i, (L, R) in enumerate(pairs):
+        assert np.array_equal(outs[i], oracle.box(L, R, 7, 64)), i
+    m.close()
+
+
+def test_multi_rejects_duplicate_devices_under_rccl():
+    with pytest.raises(oa.SadbmError) as e:
+        oa.Multi(2, devices=[0, 0])
+    assert e.value.code == -4

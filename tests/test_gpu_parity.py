@@ -22,7 +22,7 @@ def dev(a):
 
 
 def test_library_is_the_hip_build():
-    assert oa.load_library().sadbm_version() == 100
+    assert oa.load_library().sadbm_version() == 200
 
 
 def test_config1_tsukuba_golden_host_api():
@@ -62,6 +62,7 @@ def test_sweep_matches_oracle(win, D):
 def test_both_disparity_chunkings(kc, win, D, monkeypatch):
     """The matcher is instantiated for 8 and 16 disparities per thread (chosen by D); force each."""
     monkeypatch.setenv("SADBM_KC", kc)
+    oa.reload_env()                                  # the library reads its knobs once
     L, R = noise_pair(win + D, 70, 333, shift=9)
     exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
     ctx = oa.Context(0)

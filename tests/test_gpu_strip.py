@@ -124,6 +124,7 @@ def test_strip_frame_groups(shape, pairs, monkeypatch):
                 monkeypatch.delenv("SADBM_STRIP_FG", raising=False)
             else:
                 monkeypatch.setenv("SADBM_STRIP_FG", fg)
+            oa.reload_env()
             ctx = oa.Context(0)
             out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
             assert ctx.last_kernel() == ("sad_strip_kernel<%d>" % win if H > win and W > win else "none")
@@ -131,6 +132,7 @@ def test_strip_frame_groups(shape, pairs, monkeypatch):
                 bad = np.argwhere(out[i] != exp[i])
                 assert bad.size == 0, (shape, pairs, win, D, fg, i, len(bad), bad[:6])
     monkeypatch.delenv("SADBM_STRIP_FG", raising=False)
+    oa.reload_env()
     # BGR frames (plane 0) into an output batch whose rows are not 4-byte aligned
     win, D = 9, 128
     L3 = np.stack([np.stack([Ls[i], Rs[i], Ls[i]], -1) for i in range(pairs)])

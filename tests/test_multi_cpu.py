@@ -25,6 +25,18 @@ def test_band_ranges_cover_exactly(rows, nb):
     assert covered == list(range(rows))
 
 
+@pytest.mark.parametrize("rows", [0, 1, 7, 83, 4320])
+@pytest.mark.parametrize("nb", [1, 2, 3, 8])
+def test_c_abi_band_plan_equals_the_python_partition(rows, nb):
+    """sadbm_band_plan (what sadbm_compute_multi splits a frame with) == band_ranges / band_input_rows."""
+    per, ranges = oa.band_ranges(rows, nb)
+    for i, (r0, r1) in enumerate(ranges):
+        for win in (1, 7, 21):
+            a, b, c = oa.band_plan(rows, nb, win, i)
+            assert (a, b) == (r0, r1)
+            assert c == (oa.band_input_rows(r0, r1, rows, win)[1] if r1 > r0 else r0)
+
+
 def test_band_halo_is_downward_only():
     assert oa.band_input_rows(540, 1080, 4320, 21) == (540, 1100)
     assert oa.band_input_rows(3780, 4320, 4320, 21) == (3780, 4320)

@@ -167,6 +167,18 @@ int  sadbm_compute_multi_batch(sadbm_multi *m, const sadbm_image *lefts, const s
  * [*row0, *row1) and needs input rows [*row0, *in1); rows per band = ceil(rows / parts). */
 int  sadbm_band_plan(int rows, int parts, int win, int index, int *row0, int *row1, int *in1);
 
+/* Device-resident getDisparity WITHOUT any allocation.  No counterpart in the reference; it is for callers that cannot
+ * allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments and
+ * results as sadbm_compute_device, but no context: the scratch (the two padded single-channel planes the matchers
+ * read) is a static device array of SADBM_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the
+ * process ends.  Frames whose planes need more return SADBM_E_LIMIT (one 3840x2160 pair fits).  Calls no hipMalloc /
+ * hipFree / hipStreamCreate / hipEventCreate; the first call on a device resolves the array's address.  All calls on
+ * one GPU share that array: calls that overlap on one GPU (two streams, two threads) race -- serialise them. */
+#define SADBM_STATIC_SCRATCH_BYTES (19u << 20)
+int sadbm_compute_device_static(int device, const uint8_t *dL, int64_t pitchL, const uint8_t *dR, int64_t pitchR,
+                                int rows, int cols, int channels, int win, int max_disp, uint32_t flags,
+                                uint8_t *dOut, int64_t out_pitch, void *stream);
+
 /* Introspection for benchmarks (no reference counterpart): name of the matcher kernel the last call
  * on this ctx launched, and HIP-event timing of the matcher launches between profile_begin and
  * profile_end (events are recorded on the launch stream, nothing synchronises until profile_end). */

@@ -689,6 +689,64 @@ int sadbm_compute_device(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, cons
                                      flags, dOut, out_pitch, stream);
 }
 
+// ---- the entry point that allocates nothing (include/sadbm.h) ----
+// `scratch` is the device array; in host code its NAME is only a stand-in (passing it to a kernel compiles and then
+// faults), so its address on each device is resolved once with hipGetSymbolAddress and only that pointer is used.
+static __device__ __align__(256) uint8_t scratch[SADBM_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int STATIC_MAXDEV = 64;
+struct StaticDev { uint8_t *ptr = nullptr; int cus = 256; bool ready = false; };
+StaticDev g_static_dev[STATIC_MAXDEV];
+std::mutex g_static_mu;
+
+// once per device, with that device current: every GPU holds its own copy of the array at its own address
+int static_scratch_for(int device, StaticDev **out)
+{
+    if (device < 0 || device >= STATIC_MAXDEV) { snprintf(g_hip_err, sizeof(g_hip_err), "device %d out of range", device); return SADBM_E_HIP; }
+    std::lock_guard<std::mutex> guard(g_static_mu);
+    StaticDev &d = g_static_dev[device];
+    if (!d.ready) {
+        HIPCHK(hipSetDevice(device));
+        void *ptr = nullptr;
+        HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) { snprintf(g_hip_err, sizeof(g_hip_err), "hipGetSymbolAddress returned NULL"); return SADBM_E_HIP; }
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) d.cus = v;
+        d.ptr = (uint8_t *)ptr;
+        d.ready = true;
+    }
+    *out = &d;
+    return SADBM_OK;
+}
+}  // namespace
+
+int sadbm_compute_device_static(int device, const uint8_t *dL, int64_t pitchL, const uint8_t *dR, int64_t pitchR, int rows,
+                                int cols, int channels, int win, int max_disp, uint32_t flags, uint8_t *dOut,
+                                int64_t out_pitch, void *stream)
+{
+    int rc = check_params(rows, cols, channels, win, max_disp, flags);
+    if (rc) return rc;
+    if (rows == 0 || cols == 0) return SADBM_OK;
+    if (!dL || !dR || !dOut) return SADBM_E_NULL;
+    if (pitchL < (int64_t)cols * channels || pitchR < (int64_t)cols * channels || out_pitch < cols) return SADBM_E_SIZE;
+    StaticDev *sd = nullptr;
+    rc = static_scratch_for(device, &sd);
+    if (rc) return rc;
+    int nvalid = rows - win;                                  // SAD.cpp:34
+    if (nvalid < 0 || cols - win <= 0) nvalid = 0;
+    // a context that lives on this call's stack and owns nothing: its scratch is the device's static array (sd->ptr,
+    // never the array's name), which run_pipeline neither grows nor frees; too large a frame -> SADBM_E_LIMIT
+    sadbm_ctx tmp;
+    tmp.device = device;
+    tmp.planes = sd->ptr;
+    tmp.planes_cap = SADBM_STATIC_SCRATCH_BYTES;
+    tmp.planes_fixed = true;
+    tmp.cus = sd->cus;
+    return run_pipeline(&tmp, dL, pitchL, dR, pitchR, 0, 1, rows, rows, nvalid, cols, channels, win, max_disp, flags, dOut,
+                        out_pitch, 0, (hipStream_t)stream);
+}
+
 int sadbm_compute_batch_device(sadbm_ctx *ctx, const uint8_t *dL, const uint8_t *dR, int64_t pitch_in,
                                int64_t pair_stride_in, int n_pairs, int rows, int cols, int channels, int win,
                                int max_disp, uint32_t flags, uint8_t *dOut, int64_t out_pitch,

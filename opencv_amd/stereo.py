@@ -95,6 +95,7 @@ def load_library():
     L.sadbm_pipeline_wait.argtypes = [vp, i64, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(_Plane)]
     for name in ("sadbm_pipeline_create", "sadbm_pipeline_inputs", "sadbm_pipeline_submit", "sadbm_pipeline_wait"):
         getattr(L, name).restype = i32
+    L.sadbm_compute_device_static.argtypes = [i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, u32, vp, i64, vp]
     L.sadbm_multi_create.argtypes = [i32, ctypes.POINTER(i32), u32, ctypes.POINTER(vp)]
     L.sadbm_multi_destroy.argtypes = [vp]
     L.sadbm_multi_destroy.restype = None
@@ -104,7 +105,7 @@ def load_library():
     L.sadbm_band_plan.argtypes = [i32, i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.sadbm_reload_env.restype = None
     L.sadbm_thread_release.restype = None
-    for name in ("sadbm_multi_create", "sadbm_compute_multi", "sadbm_multi_device_map",
+    for name in ("sadbm_compute_device_static", "sadbm_multi_create", "sadbm_compute_multi", "sadbm_multi_device_map",
                  "sadbm_compute_multi_batch", "sadbm_band_plan"):
         getattr(L, name).restype = i32
     for name in ("sadbm_profile_begin", "sadbm_profile_end", "sadbm_create", "sadbm_get_disparity", "sadbm_get_disparity_ctx", "sadbm_compute_device",
@@ -277,6 +278,27 @@ def compute_device(left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags
     with torch.cuda.device(dev):
         _check(L.sadbm_compute_device(ctx.handle, lp, lpitch, rp, rpitch, rows, cols, ch, int(winSize), int(DSR), int(flags),
                                       out.data_ptr(), opitch, _stream_ptr(dev)))
+    return out
+
+
+def compute_device_static(left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags=0, out=None):
+    """sadbm_compute_device_static: the device path without a context and without any allocation inside the library
+    (static device scratch; frames up to one 4K pair).  `out` must be given if the caller may not allocate either."""
+    import torch
+    L = load_library()
+    lt, lp, lpitch, rows, cols, ch = _tensor_view(left)
+    rt, rp, rpitch, rrows, rcols, rch = _tensor_view(right)
+    if rch != ch:
+        raise SadbmError(-2, L.sadbm_strerror(-2).decode())
+    if rrows < rows or rcols < cols:
+        raise SadbmError(-3, L.sadbm_strerror(-3).decode())
+    dev = left.device.index or 0
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.uint8, device=left.device)
+    opitch = out.stride(0) if rows > 1 else max(cols, 1)
+    with torch.cuda.device(dev):
+        _check(L.sadbm_compute_device_static(dev, lp, lpitch, rp, rpitch, rows, cols, ch, int(winSize), int(DSR), int(flags),
+                                             out.data_ptr(), opitch, _stream_ptr(dev)))
     return out
 
 

@@ -37,8 +37,12 @@ def test_strerror_covers_codes():
     assert len(texts) == 10
 
 
-def test_multi_entry_points_validate_before_touching_a_device():
+def test_multi_and_static_entry_points_validate_before_touching_a_device():
     lib = oa.load_library()
+    assert lib.sadbm_compute_device_static(0, 1, 8, 1, 8, 8, 8, 2, 3, 8, 0, 1, 8, None) == -2     # channels
+    assert lib.sadbm_compute_device_static(0, 1, 4, 1, 8, 8, 8, 1, 3, 8, 0, 1, 8, None) == -3     # pitch < row bytes
+    assert lib.sadbm_compute_device_static(0, None, 8, 1, 8, 8, 8, 1, 3, 8, 0, 1, 8, None) == -1
+    assert lib.sadbm_compute_device_static(0, 1, 8, 1, 8, 0, 8, 1, 3, 8, 0, 1, 8, None) == 0      # empty image: nothing to do
     assert lib.sadbm_compute_multi(None, None, None, 7, 30, 0, 1, None) == -1
     a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.sadbm_band_plan(10, 0, 7, 0, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == -4

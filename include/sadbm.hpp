@@ -4,8 +4,8 @@
 // with the two file-scope parameters (SAD.cpp:9 winSize, SAD.cpp:11 DSR) made explicit arguments that
 // default to the reference's values.  Two forms:
 //   * sadbm::MatView / sadbm::Image -- a minimal owning 8-bit image for builds without OpenCV;
-//   * cv::Mat getDisparity(cv::Mat&, cv::Mat&, int, int) -- compiled only when <opencv2/core.hpp> is
-//     on the include path (it is not in this image, so that overload is untested here).
+//   * cv::Mat sadbm::getDisparity(cv::Mat&, cv::Mat&, int winSize, int DSR) -- compiled only when <opencv2/core.hpp>
+//     is on the include path (OpenCV is not in this image: tests compile it against a stub header, nothing runs it).
 // Errors: the reference surfaces bad inputs as cv::Exception thrown from inside OpenCV; here a
 // negative sadbm code becomes sadbm::Error (or cv::Exception in the cv::Mat overload).
 #ifndef SADBM_HPP
@@ -71,8 +71,11 @@ inline Image getDisparity(const Image &left, const Image &right, int winSize = k
 #if defined(__has_include)
 #if __has_include(<opencv2/core.hpp>)
 #include <opencv2/core.hpp>
-// Same name, same argument order as the reference function; paste-in replacement for SAD.cpp:24-61.
-inline cv::Mat getDisparity(cv::Mat &left, cv::Mat &right, int winSize = sadbm::kDefaultWinSize, int DSR = sadbm::kDefaultDSR)
+namespace sadbm {
+// The reference function on cv::Mat with winSize / DSR as arguments.  It lives in namespace sadbm and has NO default
+// arguments on purpose: SAD.cpp keeps its own two-argument `getDisparity(Mat&, Mat&)` (now a one-line forwarder, see
+// INTEGRATION.md), and a global overload with defaults would make the call at SAD.cpp:76 ambiguous.
+inline cv::Mat getDisparity(cv::Mat &left, cv::Mat &right, int winSize, int DSR)
 {
     CV_Assert(left.depth() == CV_8U && right.depth() == CV_8U);
     cv::Mat disparity(left.rows, left.cols, CV_8UC1, cv::Scalar(0));            // SAD.cpp:31
@@ -83,6 +86,7 @@ inline cv::Mat getDisparity(cv::Mat &left, cv::Mat &right, int winSize = sadbm::
     if (rc != SADBM_OK) CV_Error(cv::Error::StsError, sadbm::Error(rc).what());
     return disparity;
 }
+}  // namespace sadbm
 #endif
 #endif
 

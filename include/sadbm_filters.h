@@ -45,6 +45,20 @@ int sadbm_highpass_device(sadbm_ctx *ctx, const uint8_t *dSrc, int64_t src_pitch
 int sadbm_blend_device(sadbm_ctx *ctx, const uint8_t *dM1, int64_t pitch1, const uint8_t *dM2, int64_t pitch2, int rows,
                        int cols, int channels, double alpha, uint8_t *dDst, int64_t dst_pitch, void *stream);
 
+/* The two filter programs end to end on HOST buffers (device 0; H2D, kernels, D2H, synchronous) -- what their main()
+ * functions compute between imread and imshow.  Output buffers are rows x cols x channels of the source, may be NULL
+ * where a result is not wanted.
+ *   sadbm_gaus_filter_host   : gaus_filter.cpp:57-62   low = filter2D(src, G(size, sigma)); high = addWeighted(src,1,low,-1,0)
+ *   sadbm_hybrid_image_host  : hybrid_image.cpp:120-138 low = filter2D(img1, G); tmp = filter2D(img2, G);
+ *                              high = addWeighted(img2 + add, 1, tmp, -1, 0); hybrid = add(low, high, alpha)
+ * The reference's values: size 35 / sigma 3 (gaus_filter.cpp:10-11); size 31 / sigma 10, add 12, alpha 0.6
+ * (hybrid_image.cpp:10-11,131,138). */
+int sadbm_gaus_filter_host(const sadbm_image *src, int size, int sigma, uint8_t *low, int64_t low_step, uint8_t *high,
+                           int64_t high_step);
+int sadbm_hybrid_image_host(const sadbm_image *img1, const sadbm_image *img2, int size, int sigma, int add, double alpha,
+                            uint8_t *low, int64_t low_step, uint8_t *high, int64_t high_step, uint8_t *hybrid,
+                            int64_t hybrid_step);
+
 #ifdef __cplusplus
 }
 #endif

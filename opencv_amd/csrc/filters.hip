@@ -9,6 +9,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <vector>
 
 #include "../../include/sadbm_filters.h"
 #include "sadbm_internal.hpp"
@@ -218,6 +219,76 @@ int sadbm_blend_device(sadbm_ctx *ctx, const uint8_t *dM1, int64_t pitch1, const
     hipLaunchKernelGGL(blend_kernel, dim3((unsigned)((rowb + 255) / 256), rows), dim3(256), 0, (hipStream_t)stream, dM1, pitch1, dM2, pitch2,
                        rows, cols, channels, alpha, dDst, dst_pitch);
     return hipGetLastError() == hipSuccess ? SADBM_OK : SADBM_E_HIP;
+}
+
+}  // extern "C"
+
+namespace {
+// device images of one host program run: rows x pitch bytes each, freed on scope exit
+struct DevImages {
+    uint8_t *p[6] = {};
+    ~DevImages() { for (uint8_t *q : p) if (q) (void)hipFree(q); }
+};
+int check_host_image(const sadbm_image *im)
+{
+    if (!im) return SADBM_E_NULL;
+    if (im->channels != 1 && im->channels != 3 && im->channels != 4) return SADBM_E_TYPE;
+    if (im->rows < 0 || im->cols < 0 || im->rows > 65535) return SADBM_E_SIZE;
+    if (im->rows && im->cols && (!im->data || im->step < (int64_t)im->cols * im->channels)) return im->data ? SADBM_E_SIZE : SADBM_E_NULL;
+    return SADBM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int sadbm_hybrid_image_host(const sadbm_image *img1, const sadbm_image *img2, int size, int sigma, int add, double alpha,
+                            uint8_t *low, int64_t low_step, uint8_t *high, int64_t high_step, uint8_t *hybrid, int64_t hybrid_step)
+{
+    int rc = check_host_image(img1);
+    if (rc) return rc;
+    const bool two = img2 != nullptr;                          // one image: the gaus_filter program (high from the same image)
+    if (two) {
+        if ((rc = check_host_image(img2))) return rc;
+        if (img2->rows != img1->rows || img2->cols != img1->cols) return SADBM_E_SIZE;
+        if (img2->channels != img1->channels) return SADBM_E_TYPE;
+        if (hybrid && img1->channels < 3) return SADBM_E_TYPE;  // add() indexes three channels (hybrid_image.cpp:89)
+    } else if (hybrid) return SADBM_E_NULL;
+    if (size < 1 || sigma < 1 || (int64_t)size * size > MAXTAPS) return SADBM_E_PARAM;
+    const int rows = img1->rows, cols = img1->cols, ch = img1->channels;
+    if (rows == 0 || cols == 0) return SADBM_OK;
+    const size_t rowb = (size_t)cols * ch, pitch = (rowb + 255) & ~(size_t)255, bytes = pitch * rows;
+    if ((low && low_step < (int64_t)rowb) || (high && high_step < (int64_t)rowb) || (hybrid && hybrid_step < (int64_t)rowb)) return SADBM_E_SIZE;
+    std::vector<double> taps((size_t)size * size);
+    if ((rc = sadbm_gaussian_kernel(size, sigma, taps.data()))) return rc;
+    sadbm_ctx *ctx = nullptr;
+    if ((rc = sadbm_create(0, &ctx))) return rc;
+    DevImages d;                                               // 0 img1, 1 img2, 2 low, 3 tmp, 4 high, 5 hybrid
+    hipStream_t st = nullptr;                                  // the device's default stream: the copies below are synchronous
+    auto fail = [&](int code) { sadbm_destroy(ctx); return code; };
+    for (int i = 0; i < 6; ++i)
+        if (hipMalloc((void **)&d.p[i], bytes) != hipSuccess) { d.p[i] = nullptr; return fail(SADBM_E_ALLOC); }
+    if (hipMemcpy2D(d.p[0], pitch, img1->data, (size_t)img1->step, rowb, rows, hipMemcpyHostToDevice) != hipSuccess) return fail(SADBM_E_HIP);
+    const sadbm_image *src2 = two ? img2 : img1;
+    if (hipMemcpy2D(d.p[1], pitch, src2->data, (size_t)src2->step, rowb, rows, hipMemcpyHostToDevice) != hipSuccess) return fail(SADBM_E_HIP);
+    if ((rc = sadbm_filter2d_device(ctx, d.p[0], (int64_t)pitch, rows, cols, ch, taps.data(), size, size, d.p[2], (int64_t)pitch, st))) return fail(rc);
+    const uint8_t *blur2 = d.p[2];
+    if (two) {
+        if ((rc = sadbm_filter2d_device(ctx, d.p[1], (int64_t)pitch, rows, cols, ch, taps.data(), size, size, d.p[3], (int64_t)pitch, st))) return fail(rc);
+        blur2 = d.p[3];
+    }
+    if ((rc = sadbm_highpass_device(ctx, d.p[1], (int64_t)pitch, blur2, (int64_t)pitch, rows, (int)rowb, add, d.p[4], (int64_t)pitch, st))) return fail(rc);
+    if (hybrid && (rc = sadbm_blend_device(ctx, d.p[2], (int64_t)pitch, d.p[4], (int64_t)pitch, rows, cols, ch, alpha, d.p[5], (int64_t)pitch, st))) return fail(rc);
+    if (low && hipMemcpy2D(low, (size_t)low_step, d.p[2], pitch, rowb, rows, hipMemcpyDeviceToHost) != hipSuccess) return fail(SADBM_E_HIP);
+    if (high && hipMemcpy2D(high, (size_t)high_step, d.p[4], pitch, rowb, rows, hipMemcpyDeviceToHost) != hipSuccess) return fail(SADBM_E_HIP);
+    if (hybrid && hipMemcpy2D(hybrid, (size_t)hybrid_step, d.p[5], pitch, rowb, rows, hipMemcpyDeviceToHost) != hipSuccess) return fail(SADBM_E_HIP);
+    if (hipDeviceSynchronize() != hipSuccess) return fail(SADBM_E_HIP);
+    sadbm_destroy(ctx);
+    return SADBM_OK;
+}
+
+int sadbm_gaus_filter_host(const sadbm_image *src, int size, int sigma, uint8_t *low, int64_t low_step, uint8_t *high, int64_t high_step)
+{
+    return sadbm_hybrid_image_host(src, nullptr, size, sigma, 0, 0.0, low, low_step, high, high_step, nullptr, 0);
 }
 
 }  // extern "C"

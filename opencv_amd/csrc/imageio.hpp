@@ -6,7 +6,9 @@
 // (imread would replicate grey into B, G and R; channel 0 is the same plane either way).
 //   read : binary PGM (P5) / PPM (P6); PNG, non-interlaced, colour types 0/2/3/4/6, bit depths 1..16
 //          (16-bit samples keep their high byte, alpha is dropped -- as imread does without ANYDEPTH/UNCHANGED)
-//   write: binary PGM / PPM; PNG (8-bit grey or RGB, stored deflate blocks)
+//          BMP (what gaus_filter.cpp:44 / hybrid_image.cpp:104-105 load): BITMAPINFOHEADER family, uncompressed, 8-bit
+//          paletted / 24-bit / 32-bit, bottom-up or top-down; BMP stores BGR, which is what imread returns
+//   write: binary PGM / PPM; PNG (8-bit grey or RGB, stored deflate blocks); 24-bit BMP
 // Written from the PNG (ISO/IEC 15948) and DEFLATE (RFC 1951) / zlib (RFC 1950) specifications.
 #ifndef SADBM_IMAGEIO_HPP
 #define SADBM_IMAGEIO_HPP
@@ -358,12 +360,76 @@ inline Bytes encode_pnm(const sadbm::Image &img)
     return out;
 }
 
+// ---------------------------------------------------------------------------------------------
+// BMP (uncompressed): the input format of the reference's filter programs (gaus_filter.cpp:44, hybrid_image.cpp:104-105)
+// ---------------------------------------------------------------------------------------------
+inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint32_t le16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+inline bool decode_bmp(const Bytes &file, sadbm::Image &img, std::string &err)
+{
+    if (file.size() < 54 || file[0] != 'B' || file[1] != 'M') { err = "not a BMP file"; return false; }
+    const uint32_t off = le32(&file[10]), hdr = le32(&file[14]);
+    if (hdr < 40 || (size_t)14 + hdr > file.size()) { err = "unsupported BMP header"; return false; }
+    const int32_t w = (int32_t)le32(&file[18]), hs = (int32_t)le32(&file[22]);
+    const uint32_t planes = le16(&file[26]), bpp = le16(&file[28]), comp = le32(&file[30]);
+    uint32_t ncol = le32(&file[46]);
+    const bool top_down = hs < 0;
+    const int64_t h = top_down ? -(int64_t)hs : hs;
+    if (planes != 1 || w <= 0 || h <= 0 || w > 65535 || h > 65535) { err = "bad BMP dimensions"; return false; }
+    if (comp != 0 && !(comp == 3 && bpp == 32)) { err = "compressed BMP is not supported"; return false; }
+    if (bpp != 8 && bpp != 24 && bpp != 32) { err = "only 8-, 24- and 32-bit BMP is supported"; return false; }
+    const size_t stride = (((size_t)w * bpp + 31) / 32) * 4;
+    if (off > file.size() || (file.size() - off) / stride < (size_t)h) { err = "BMP pixel data too short"; return false; }
+    const uint8_t *pal = nullptr;
+    bool grey_palette = true;
+    if (bpp == 8) {
+        if (ncol == 0) ncol = 256;
+        if (ncol > 256 || (size_t)14 + hdr + (size_t)ncol * 4 > file.size()) { err = "bad BMP palette"; return false; }
+        pal = &file[14 + hdr];
+        for (uint32_t i = 0; i < ncol; ++i) grey_palette = grey_palette && pal[4 * i] == pal[4 * i + 1] && pal[4 * i] == pal[4 * i + 2];
+    }
+    // imread(IMREAD_COLOR) always returns 3 channels; a grey palette stays 1-channel here (channel 0 is the same plane)
+    const int ch = (bpp == 8 && grey_palette) ? 1 : 3;
+    img = sadbm::Image((int)h, w, ch);
+    for (int64_t y = 0; y < h; ++y) {
+        const uint8_t *src = &file[off + (size_t)(top_down ? y : h - 1 - y) * stride];
+        uint8_t *dst = img.ptr((int)y);
+        if (bpp == 24) memcpy(dst, src, (size_t)w * 3);                                   // already B, G, R
+        else if (bpp == 32) for (int x = 0; x < w; ++x) { dst[3 * x] = src[4 * x]; dst[3 * x + 1] = src[4 * x + 1]; dst[3 * x + 2] = src[4 * x + 2]; }
+        else for (int x = 0; x < w; ++x) {
+            const uint32_t idx = src[x] < ncol ? src[x] : 0;
+            if (ch == 1) dst[x] = pal[4 * idx];
+            else { dst[3 * x] = pal[4 * idx]; dst[3 * x + 1] = pal[4 * idx + 1]; dst[3 * x + 2] = pal[4 * idx + 2]; }
+        }
+    }
+    return true;
+}
+
+inline Bytes encode_bmp(const sadbm::Image &img)
+{
+    const size_t stride = (((size_t)img.cols * 24 + 31) / 32) * 4, data = stride * (size_t)img.rows;
+    Bytes out(54 + data, 0);
+    auto put32 = [&](size_t at, uint32_t v) { out[at] = (uint8_t)v; out[at + 1] = (uint8_t)(v >> 8); out[at + 2] = (uint8_t)(v >> 16); out[at + 3] = (uint8_t)(v >> 24); };
+    out[0] = 'B'; out[1] = 'M';
+    put32(2, (uint32_t)out.size()); put32(10, 54); put32(14, 40); put32(18, (uint32_t)img.cols); put32(22, (uint32_t)img.rows);
+    out[26] = 1; out[28] = 24; put32(34, (uint32_t)data); put32(38, 2834); put32(42, 2834);
+    for (int y = 0; y < img.rows; ++y) {
+        uint8_t *dst = &out[54 + (size_t)(img.rows - 1 - y) * stride];
+        const uint8_t *src = img.ptr(y);
+        if (img.channels == 3) memcpy(dst, src, (size_t)img.cols * 3);
+        else for (int x = 0; x < img.cols; ++x) dst[3 * x] = dst[3 * x + 1] = dst[3 * x + 2] = src[x];
+    }
+    return out;
+}
+
 // imread(path) of SAD.cpp:65-66: false (and a message) instead of an empty Mat.
 inline bool read_image(const char *path, sadbm::Image &img, std::string &err)
 {
     Bytes file;
     if (!read_file(path, file)) { err = std::string("cannot open ") + path; return false; }
     if (file.size() >= 2 && file[0] == 'P' && (file[1] == '5' || file[1] == '6')) return decode_pnm(file, img, err);
+    if (file.size() >= 2 && file[0] == 'B' && file[1] == 'M') return decode_bmp(file, img, err);
     return decode_png(file, img, err);
 }
 
@@ -372,7 +438,8 @@ inline bool write_image(const char *path, const sadbm::Image &img, std::string &
     const size_t n = strlen(path);
     const bool png = n >= 4 && !strcmp(path + n - 4, ".png");
     if (img.channels != 1 && img.channels != 3) { err = "only 1- and 3-channel images can be written"; return false; }
-    const Bytes data = png ? encode_png(img) : encode_pnm(img);
+    const bool bmp = n >= 4 && !strcmp(path + n - 4, ".bmp");
+    const Bytes data = png ? encode_png(img) : bmp ? encode_bmp(img) : encode_pnm(img);
     FILE *f = fopen(path, "wb");
     if (!f) { err = std::string("cannot write ") + path; return false; }
     const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();

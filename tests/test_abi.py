@@ -95,3 +95,22 @@ def test_argument_validation_happens_before_device_use():
     b = lib.sadbm_compute_band_device
     assert b(fake, 1, 8, 1, 8, 16, 4, 5, 4, 8, 1, 3, 8, 0, 1, 8, None) == -3   # rows_in < rows_out + win - 1
     assert b(fake, 1, 8, 1, 8, 16, 14, 4, 2, 8, 1, 3, 8, 0, 1, 8, None) == -3  # band beyond the frame
+
+
+def test_cv_mat_adapter_compiles_and_the_paste_in_is_unambiguous(tmp_path):
+    """include/sadbm.hpp's cv::Mat adapter + the INTEGRATION.md paste-in (SAD.cpp:13-61 replaced, main() kept) compile
+    against tests/stubs/opencv2/core.hpp -- a stub, OpenCV is absent -- so a typo or an ambiguous overload is caught."""
+    import subprocess
+    src = tmp_path / "paste_in.cpp"
+    src.write_text("""
+#include <opencv2/core.hpp>
+using namespace cv;
+int winSize = 7;            // SAD.cpp:9
+int DSR = 30;               // SAD.cpp:11
+#include "sadbm.hpp"
+Mat getDisparity(Mat &left, Mat &right) { return sadbm::getDisparity(left, right, winSize, DSR); }
+int main() { Mat left, right; Mat Disparity = getDisparity(left, right); return Disparity.rows; }   // SAD.cpp:76
+""")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "stubs"),
+                        "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -93,6 +93,52 @@ def test_bad_files_are_rejected(tmp_path):
     assert run("onlyone.png").returncode == 2
 
 
+def test_bmp_reader_on_the_reference_pictures(tmp_path):
+    """cat.bmp / dog.bmp (byte copies of the reference's test_picture/ files): the BMP reader's pixels equal the PIL decode
+    recorded by tests/golden/make_filter_golden.py; BMP -> PNG -> BMP keeps every pixel."""
+    need_cli()
+    import hashlib
+    import json
+    meta = json.load(open(GOLDEN + "/filters_golden.json"))
+    for n in ("cat", "dog"):
+        ppm, png, bmp = str(tmp_path / (n + ".ppm")), str(tmp_path / (n + ".png")), str(tmp_path / (n + "2.bmp"))
+        assert run("--convert", "%s/%s.bmp" % (GOLDEN, n), ppm).returncode == 0
+        rgb = read_pnm(ppm)
+        assert list(rgb.shape) == meta[n + "_shape"]
+        assert hashlib.sha256(np.ascontiguousarray(rgb[:, :, ::-1]).tobytes()).hexdigest() == meta[n + "_bgr_sha256"]
+        assert run("--convert", ppm, png).returncode == 0 and run("--convert", png, bmp).returncode == 0
+        back = str(tmp_path / "back.ppm")
+        assert run("--convert", bmp, back).returncode == 0
+        assert np.array_equal(read_pnm(back), rgb)
+
+
+@pytest.mark.gpu
+def test_cli_filter_programs_on_the_reference_pictures(tmp_path):
+    """`sadbm_cli --gaus` / `--hybrid` = main() of gaus_filter.cpp:42-70 / hybrid_image.cpp:102-143 on the reference's own
+    pictures, with the programs' own parameters, against the oracle outputs committed under tests/golden/."""
+    need_cli()
+    import hashlib
+    import json
+    meta = json.load(open(GOLDEN + "/filters_golden.json"))
+
+    def bgr_sha(path):
+        ppm = str(tmp_path / "t.ppm")
+        assert run("--convert", path, ppm).returncode == 0
+        return hashlib.sha256(np.ascontiguousarray(read_pnm(ppm)[:, :, ::-1]).tobytes()).hexdigest()
+
+    low, high = str(tmp_path / "low.bmp"), str(tmp_path / "high.png")
+    r = run("--gaus", GOLDEN + "/cat.bmp", "-o", low, "--high", high)
+    assert r.returncode == 0, r.stderr
+    assert bgr_sha(low) == meta["gaus_cat_low_sha256"] == bgr_sha(GOLDEN + "/gaus_cat_low.png")
+    assert bgr_sha(high) == meta["gaus_cat_high_sha256"]
+    mix, low, high = str(tmp_path / "mix.bmp"), str(tmp_path / "l.bmp"), str(tmp_path / "h.bmp")
+    r = run("--hybrid", GOLDEN + "/dog.bmp", GOLDEN + "/cat.bmp", "-o", mix, "--low", low, "--high", high)
+    assert r.returncode == 0, r.stderr
+    assert bgr_sha(low) == meta["hybrid_dog_low_sha256"]
+    assert bgr_sha(high) == meta["hybrid_cat_high_sha256"]
+    assert bgr_sha(mix) == meta["hybrid_dog_cat_sha256"] == bgr_sha(GOLDEN + "/hybrid_dog_cat.png")
+
+
 @pytest.mark.gpu
 def test_cli_config1_from_reference_pngs(tmp_path):
     """BASELINE config 1 end to end: the reference's PNG pair, defaults winSize=7 DSR=30, output == golden map."""

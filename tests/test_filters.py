@@ -44,6 +44,26 @@ def test_highpass_and_blend_definitions():
     assert np.array_equal(bl[1:-1, 1:-1], inner.astype(np.uint8))
 
 
+def test_filter_oracle_reproduces_the_committed_outputs_on_the_reference_pictures():
+    """tests/golden/{gaus,hybrid}_*.png were produced by tests/golden/make_filter_golden.py from cat.bmp / dog.bmp."""
+    import json
+    import os
+    from helpers import GOLDEN, sha
+    Image = pytest.importorskip("PIL.Image")
+    meta = json.load(open(os.path.join(GOLDEN, "filters_golden.json")))
+    cat = np.ascontiguousarray(np.asarray(Image.open(os.path.join(GOLDEN, "cat.bmp")).convert("RGB"))[:, :, ::-1])
+    dog = np.ascontiguousarray(np.asarray(Image.open(os.path.join(GOLDEN, "dog.bmp")).convert("RGB"))[:, :, ::-1])
+    assert sha(cat) == meta["cat_bgr_sha256"] and sha(dog) == meta["dog_bgr_sha256"]
+    k = F.gaussian_kernel(31, 10)
+    low = F.filter2d(dog, k)
+    high = F.highpass(cat, F.filter2d(cat, k), 12)
+    assert sha(low) == meta["hybrid_dog_low_sha256"] and sha(high) == meta["hybrid_cat_high_sha256"]
+    mix = F.blend(low, high, 0.6)
+    assert sha(mix) == meta["hybrid_dog_cat_sha256"]
+    stored = np.asarray(Image.open(os.path.join(GOLDEN, "hybrid_dog_cat.png")).convert("RGB"))[:, :, ::-1]
+    assert np.array_equal(stored, mix)
+
+
 def _dev(a):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()

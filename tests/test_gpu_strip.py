@@ -71,12 +71,35 @@ def test_strip_full_size_4k_band():
     assert np.array_equal(got[r0: r0 + n], exp)
 
 
+def test_strip_32_disparity_blocks_batches_bands_and_borders():
+    """The 128-thread / 32-disparity form of the strip matcher (D <= 32: the reference's own DSR = 30): batches with frame
+    groups, a row band, BGR, D not a multiple of 16, binary dots (ties), the reference's own pair."""
+    import torch
+    from helpers import tsukuba_bgr
+    for (H, W, n, win, D) in ((61, 517, 5, 7, 30), (40, 1242, 3, 9, 32), (90, 384, 8, 7, 17), (33, 260, 4, 15, 31), (50, 300, 2, 21, 24)):
+        Ls, Rs = zip(*[oracle.rds(70 + i, W, H, 2 + i, min(D - 1, 12 + i), i & 1) for i in range(n)])
+        ctx = oa.Context(0)
+        out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel() == "sad_strip_kernel<%d>" % win
+        for i in range(n):
+            assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), (H, W, win, D, i)
+        r0, nb = H // 3, H // 3
+        i1 = min(r0 + nb + win - 1, H)
+        got = oa.compute_band_device(dev(Ls[0][r0:i1]), dev(Rs[0][r0:i1]), H, r0, nb, win, D, oa.KERNEL_STRIP).cpu().numpy()
+        assert np.array_equal(got, oracle.box(Ls[0], Rs[0], win, D)[r0:r0 + nb]), (H, W, win, D, "band")
+    L, R = tsukuba_bgr()
+    exp = oracle.literal(np.ascontiguousarray(L[:, :, 0]), np.ascontiguousarray(R[:, :, 0]), 7, 30)
+    assert np.array_equal(oa.compute_device(dev(L), dev(R), 7, 30, oa.KERNEL_STRIP).cpu().numpy(), exp)
+    Lf, Rf = oracle.rds(2, 1920, 1080, 4, 20, 0)                 # a full 1080p frame at the reference's parameters
+    assert np.array_equal(oa.compute_device(dev(Lf), dev(Rf), 7, 30, oa.KERNEL_STRIP).cpu().numpy(), oracle.box(Lf, Rf, 7, 30))
+
+
 @pytest.mark.parametrize("shape", [(9, 300), (300, 9), (40, 17), (8, 8), (16, 50), (50, 16), (1, 1), (33, 129), (20, 255), (20, 257), (20, 513)])
 def test_strip_small_and_degenerate_shapes(shape):
     """Shapes around the strip (16), block (256) and window sizes, W < D, W <= win, H <= win -- forced strip matcher."""
     H, W = shape
     L, R = noise_pair(H * 31 + W, H, W)
-    for win, D in ((7, 30), (4, 64), (9, 256), (15, 100), (21, 65)):
+    for win, D in ((7, 30), (4, 64), (9, 256), (15, 100), (21, 65), (13, 32), (5, 3)):
         exp = oracle.literal(L, R, win, D)
         got = oa.get_disparity_host(L, R, win, D, oa.KERNEL_STRIP)
         assert np.array_equal(got, exp), (shape, win, D)
@@ -101,7 +124,7 @@ def test_strip_constant_identical_and_binary_ties():
 def test_strip_every_window_instantiation(win):
     """Every window the strip matcher is instantiated for (its geometry is constexpr per WIN), at 64 / 128 / 256 disparity blocks."""
     L, R = noise_pair(900 + win, 57, 283, shift=7)
-    for D in (50, 97, 256):
+    for D in (9, 30, 32, 50, 97, 256):                             # 32- (two classes per wave), 64-, 128- and 256-disparity blocks
         ctx = oa.Context(0)
         got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
         assert ctx.last_kernel() == "sad_strip_kernel<%d>" % win

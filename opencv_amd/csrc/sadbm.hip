@@ -23,6 +23,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <immintrin.h>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -249,10 +250,52 @@ int grow_pinned(uint8_t **buf, size_t *cap, size_t need)
 
 // Row-wise host copy between a caller's (pageable, strided) image and pinned staging.  Large frames are split over
 // a few threads: one core copies ~10 GB/s, which would otherwise bound the host API (a 4K pair is 25 MB per call).
-void copy_rows(uint8_t *dst, int64_t dstep, const uint8_t *src, int64_t sstep, size_t rowb, int rows)
+// Channel 0 of `cols` interleaved pixels (ch = 3: BGR as cv::imread hands the reference, SAD.cpp:65-66; ch = 4: BGRA).  The
+// matcher reads channel 0 only (SAD.cpp:19-20), so the host API gathers that plane while it copies the caller's rows into
+// pinned memory anyway: a third / a quarter of the bytes then cross PCIe.  SSSE3 byte shuffles, 16 pixels per step.
+__attribute__((target("ssse3"))) void extract_ch0_ssse3(uint8_t *dst, const uint8_t *src, int cols, int ch)
 {
-    auto body = [=](int y0, int y1) { for (int y = y0; y < y1; ++y) memcpy(dst + (int64_t)y * dstep, src + (int64_t)y * sstep, rowb); };
-    const size_t bytes = rowb * (size_t)rows;
+    int x = 0;
+    if (ch == 3) {
+        const __m128i m0 = _mm_setr_epi8(0, 3, 6, 9, 12, 15, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+        const __m128i m1 = _mm_setr_epi8(-1, -1, -1, -1, -1, -1, 2, 5, 8, 11, 14, -1, -1, -1, -1, -1);
+        const __m128i m2 = _mm_setr_epi8(-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 1, 4, 7, 10, 13);
+        for (; x + 16 <= cols; x += 16) {
+            const __m128i a = _mm_loadu_si128((const __m128i *)(src + 3 * x)), b = _mm_loadu_si128((const __m128i *)(src + 3 * x + 16)),
+                          c = _mm_loadu_si128((const __m128i *)(src + 3 * x + 32));
+            _mm_storeu_si128((__m128i *)(dst + x), _mm_or_si128(_mm_or_si128(_mm_shuffle_epi8(a, m0), _mm_shuffle_epi8(b, m1)), _mm_shuffle_epi8(c, m2)));
+        }
+    } else if (ch == 4) {
+        const __m128i m = _mm_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+        for (; x + 16 <= cols; x += 16) {
+            const __m128i a = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(src + 4 * x)), m);
+            const __m128i b = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(src + 4 * x + 16)), m);
+            const __m128i c = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(src + 4 * x + 32)), m);
+            const __m128i d = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(src + 4 * x + 48)), m);
+            _mm_storeu_si128((__m128i *)(dst + x), _mm_unpacklo_epi64(_mm_unpacklo_epi32(a, b), _mm_unpacklo_epi32(c, d)));
+        }
+    }
+    for (; x < cols; ++x) dst[x] = src[(size_t)x * ch];
+}
+void extract_ch0(uint8_t *dst, const uint8_t *src, int cols, int ch)
+{
+    static const bool ssse3 = __builtin_cpu_supports("ssse3");
+    if (ssse3) { extract_ch0_ssse3(dst, src, cols, ch); return; }
+    for (int x = 0; x < cols; ++x) dst[x] = src[(size_t)x * ch];
+}
+
+// Row-wise host copy between a caller's (pageable, strided) image and pinned staging; ch > 1: channel 0 of `rowb` pixels
+// instead of `rowb` bytes.  Large frames are split over a few threads: one core copies ~10 GB/s, which would otherwise
+// bound the host API (a 4K pair is 25 MB per call).
+void copy_rows(uint8_t *dst, int64_t dstep, const uint8_t *src, int64_t sstep, size_t rowb, int rows, int ch = 1)
+{
+    auto body = [=](int y0, int y1) {
+        for (int y = y0; y < y1; ++y) {
+            if (ch == 1) memcpy(dst + (int64_t)y * dstep, src + (int64_t)y * sstep, rowb);
+            else extract_ch0(dst + (int64_t)y * dstep, src + (int64_t)y * sstep, (int)rowb, ch);
+        }
+    };
+    const size_t bytes = rowb * (size_t)rows * (size_t)ch;
     unsigned hw = std::thread::hardware_concurrency();
     int nt = bytes >= ((size_t)4 << 20) ? (int)(bytes >> 21) : 1;      // one thread per 2 MB, at most 8
     if (nt > 8) nt = 8;
@@ -789,10 +832,11 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
     const size_t rowb = (size_t)cols * ch;
     if (left->step < (int64_t)rowb || right->step < (int64_t)rowb || out->step < cols) return SADBM_E_SIZE;
     HIPCHK(hipSetDevice(ctx->device));
-    const size_t pin = (rowb + 255) & ~(size_t)255, pout = ((size_t)cols + 255) & ~(size_t)255;
+    // colour inputs: only channel 0 is ever read (SAD.cpp:19-20) -- it is gathered while the rows are copied to pinned memory
+    const size_t pin = ((size_t)cols + 255) & ~(size_t)255, pout = pin;
     const size_t in_bytes = 2 * pin * rows, out_bytes = pout * rows;
     // Small frames (the reference's own 384x288 pair): the GPU reads the pinned staging buffer and writes the pinned
-    // result directly over PCIe -- three DMA set-ups (2 x H2D, 1 x D2H) cost more than the 0.8 MB they would move.
+    // result directly over PCIe -- three DMA set-ups (2 x H2D, 1 x D2H) cost more than the bytes they would move.
     const bool zero_copy = (long)in_bytes <= env().zc_bytes;
     rc = grow_pinned(&ctx->pin_in, &ctx->pin_in_cap, in_bytes);
     if (rc) return rc;
@@ -816,12 +860,12 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
     // caller's (pageable, strided) rows -> pinned staging (-> device: one copy for both images; frames of several MB
     // are sent one by one so that the R rows are gathered while the L transfer runs)
     const bool split = !zero_copy && in_bytes > ((size_t)8 << 20);
-    copy_rows(hL, (int64_t)pin, left->data, left->step, rowb, rows);
+    copy_rows(hL, (int64_t)pin, left->data, left->step, (size_t)cols, rows, ch);
     if (split) HIPCHK(hipMemcpyAsync(dL, hL, pin * rows, hipMemcpyHostToDevice, st));
-    copy_rows(hR, (int64_t)pin, right->data, right->step, rowb, rows);
+    copy_rows(hR, (int64_t)pin, right->data, right->step, (size_t)cols, rows, ch);
     if (split) HIPCHK(hipMemcpyAsync(dR, hR, pin * rows, hipMemcpyHostToDevice, st));
     else if (!zero_copy) HIPCHK(hipMemcpyAsync(dL, hL, in_bytes, hipMemcpyHostToDevice, st));
-    rc = sadbm_compute_device(ctx, dL, (int64_t)pin, dR, (int64_t)pin, rows, cols, ch, win, max_disp, flags, dO, (int64_t)pout, st);
+    rc = sadbm_compute_device(ctx, dL, (int64_t)pin, dR, (int64_t)pin, rows, cols, 1, win, max_disp, flags, dO, (int64_t)pout, st);
     if (rc) return rc;
     if (!zero_copy) HIPCHK(hipMemcpyAsync(ctx->pin_out, dO, out_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--split", default="batch", choices=["batch", "bands"],
                     help="batch: every rank its own pairs, no collective (weak scaling); bands: ONE frame split into "
                          "row bands + one RCCL all-gather per frame (strong scaling, BASELINE config 4)")
+    ap.add_argument("--sub-bands", type=int, default=1, help="--split bands: compute the band in this many pieces and gather each "
+                                                              "finished piece asynchronously while the next one is computed")
     ap.add_argument("--no-verify", action="store_true", help="skip the whole-batch comparison with the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines, the verification and the extra single-GPU legs")
     ap.add_argument("--no-extras", action="store_true", help="skip the latency and 1080p legs")
@@ -165,7 +167,8 @@ def main():
             return oa.compute_band_device(lbt, rbt, frame_rows, row0, rows_out, w, d, flags, out=out, ctx=ctx)
 
         def step():
-            full[0] = oa.disparity_row_bands(dLb, dRb, H, win, D, rank, world, flags=args.flags, compute_band=compute_band)
+            full[0] = oa.disparity_row_bands(dLb, dRb, H, win, D, rank, world, flags=args.flags, compute_band=compute_band,
+                                             sub_bands=args.sub_bands)
     else:
         Ls, Rs = [], []
         for i in range(pairs):

@@ -28,10 +28,15 @@ def scatter_band(frame_left, frame_right, rank, world, win):
 
 
 def disparity_row_bands(left_band, right_band, frame_rows, win, max_disp, rank, world, group=None, flags=0,
-                        compute_band=None):
+                        compute_band=None, sub_bands=1, dst=None):
     """Band compute + one all-gather.  left_band/right_band: this rank's input rows (band + halo) as
     torch uint8 tensors on the rank's device.  Returns the full frame_rows x cols disparity map
-    (identical on every rank)."""
+    (identical on every rank).
+
+    sub_bands > 1 pipelines the exchange (over xGMI a ring gather of config 4's bands takes about as long as a
+    GPU's share of the compute): the band is computed in sub_bands pieces and the all-gather of a finished piece is issued
+    asynchronously, so it runs while the next piece is computed.  Every piece is gathered straight into its place in the map.
+    dst = a rank: gather to that rank only (the others return None) -- for callers where one GPU or the host consumes the map."""
     import torch
     import torch.distributed as dist
     if compute_band is None:
@@ -40,11 +45,33 @@ def disparity_row_bands(left_band, right_band, frame_rows, win, max_disp, rank, 
     per, ranges = band_ranges(frame_rows, world)
     r0, r1 = ranges[rank]
     # equal counts for the all-gather: every rank contributes `per` rows (short/empty bands are zero-padded)
-    send = torch.zeros((per, cols), dtype=torch.uint8, device=left_band.device)
-    if r1 > r0:
-        compute_band(left_band, right_band, frame_rows, r0, r1 - r0, win, max_disp, flags, out=send[: r1 - r0])
     if world == 1:
+        send = torch.zeros((per, cols), dtype=torch.uint8, device=left_band.device)
+        if r1 > r0:
+            compute_band(left_band, right_band, frame_rows, r0, r1 - r0, win, max_disp, flags, out=send[: r1 - r0])
         return send[:frame_rows]
-    full = torch.empty((world * per, cols), dtype=torch.uint8, device=left_band.device)
-    dist.all_gather_into_tensor(full, send, group=group)
-    return full[:frame_rows]
+    root = dst is None or dst == rank
+    full = torch.zeros((world * per, cols), dtype=torch.uint8, device=left_band.device) if root else None
+    send = full[rank * per:(rank + 1) * per] if root else torch.zeros((per, cols), dtype=torch.uint8, device=left_band.device)
+    sub_bands = max(1, min(int(sub_bands), per))
+    sper = -(-per // sub_bands)
+    works = []
+    for s in range(sub_bands):
+        p0, p1 = s * sper, min((s + 1) * sper, per)           # rows of the band slot, the same on every rank
+        if p1 <= p0:
+            break
+        s0, s1 = r0 + p0, min(r0 + p1, r1)                    # frame rows of this piece that exist on this rank
+        if s1 > s0:
+            i1 = min(s1 + win - 1, frame_rows)
+            compute_band(left_band[s0 - r0:i1 - r0], right_band[s0 - r0:i1 - r0], frame_rows, s0, s1 - s0, win, max_disp, flags,
+                         out=send[p0:p0 + (s1 - s0)])
+        piece = send[p0:p1]
+        if dst is None:
+            outs = [full[r * per + p0:r * per + p1] for r in range(world)]     # contiguous row ranges of the map
+            works.append(dist.all_gather(outs, piece, group=group, async_op=True))
+        else:
+            outs = [full[r * per + p0:r * per + p1] for r in range(world)] if root else None
+            works.append(dist.gather(piece, outs, dst=dst, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    return full[:frame_rows] if root else None

@@ -71,7 +71,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, H, W, win, D, q):
+def _worker(rank, world, port, H, W, win, D, q, sub_bands=1, dst=None):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -85,8 +85,8 @@ def _worker(rank, world, port, H, W, win, D, q):
         return out
 
     (r0, r1, per), lb, rb = oa.scatter_band(torch.from_numpy(L), torch.from_numpy(R), rank, world, win)
-    full = oa.disparity_row_bands(lb.contiguous(), rb.contiguous(), H, win, D, rank, world, compute_band=cpu_band)
-    q.put((rank, full.numpy().copy()))
+    full = oa.disparity_row_bands(lb.contiguous(), rb.contiguous(), H, win, D, rank, world, compute_band=cpu_band, sub_bands=sub_bands, dst=dst)
+    q.put((rank, None if full is None else full.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -109,3 +109,28 @@ def test_row_bands_all_gather_gloo_world2(H):
     exp = oracle.literal(L, R, win, D)
     for r in range(world):
         assert np.array_equal(outs[r], exp), r
+
+
+@pytest.mark.parametrize("H,sub_bands,dst", [(41, 3, None), (40, 20, None), (37, 2, 1), (9, 4, 0)])
+def test_row_bands_pipelined_gather_and_gather_to_one_gloo_world2(H, sub_bands, dst):
+    """sub_bands > 1: pieces of the band are gathered asynchronously while the next one is computed; dst: only that rank
+    receives the map.  Bands shorter than the window and sub-bands of a single row included."""
+    import torch.multiprocessing as mp
+    W, win, D, world = 52, 7, 16, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, W, win, D, q, sub_bands, dst)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    L, R = noise_pair(99, H, W, shift=4)
+    exp = oracle.literal(L, R, win, D)
+    for r in range(world):
+        if dst is None or r == dst:
+            assert np.array_equal(outs[r], exp), r
+        else:
+            assert outs[r] is None

@@ -50,6 +50,16 @@ def disparity_row_bands(left_band, right_band, frame_rows, win, max_disp, rank, 
         if r1 > r0:
             compute_band(left_band, right_band, frame_rows, r0, r1 - r0, win, max_disp, flags, out=send[: r1 - r0])
         return send[:frame_rows]
+    if sub_bands <= 1 and dst is None:
+        # the plain form: whole band, then ONE all-gather of equal-sized u8 bands
+        send = torch.zeros((per, cols), dtype=torch.uint8, device=left_band.device)
+        if r1 > r0:
+            compute_band(left_band, right_band, frame_rows, r0, r1 - r0, win, max_disp, flags, out=send[: r1 - r0])
+        full = torch.empty((world * per, cols), dtype=torch.uint8, device=left_band.device)
+        dist.all_gather_into_tensor(full, send, group=group)
+        return full[:frame_rows]
+    # overlap needs a backend whose collectives run beside the compute stream (RCCL); elsewhere each piece is waited for at once
+    overlap = dist.get_backend(group) == "nccl" or not left_band.is_cuda
     root = dst is None or dst == rank
     full = torch.zeros((world * per, cols), dtype=torch.uint8, device=left_band.device) if root else None
     send = full[rank * per:(rank + 1) * per] if root else torch.zeros((per, cols), dtype=torch.uint8, device=left_band.device)
@@ -72,6 +82,8 @@ def disparity_row_bands(left_band, right_band, frame_rows, win, max_disp, rank, 
         else:
             outs = [full[r * per + p0:r * per + p1] for r in range(world)] if root else None
             works.append(dist.gather(piece, outs, dst=dst, group=group, async_op=True))
+        if not overlap:
+            works.pop().wait()
     for w in works:
         w.wait()
     return full[:frame_rows] if root else None

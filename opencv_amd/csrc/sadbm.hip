@@ -203,6 +203,7 @@ struct sadbm_ctx {
     size_t stage_out_cap = 0;
     uint8_t *pin_in = nullptr, *pin_out = nullptr;   // pinned host staging of the host API (pageable -> device copies are ~20x slower)
     size_t pin_in_cap = 0, pin_out_cap = 0;
+    uint8_t *pin_in_dev = nullptr, *pin_out_dev = nullptr;   // device addresses of the pinned buffers (zero-copy path), resolved when they grow
     double *taps = nullptr;                // filter taps of sadbm_filter2d_device (filters.hip), one buffer per context
     char last_kernel[64] = "none";
     int cus = 256;                         // compute units of the device (grid shaping)
@@ -838,17 +839,22 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
     // Small frames (the reference's own 384x288 pair): the GPU reads the pinned staging buffer and writes the pinned
     // result directly over PCIe -- three DMA set-ups (2 x H2D, 1 x D2H) cost more than the bytes they would move.
     const bool zero_copy = (long)in_bytes <= env().zc_bytes;
+    if (ctx->pin_in_cap < in_bytes) ctx->pin_in_dev = nullptr;
     rc = grow_pinned(&ctx->pin_in, &ctx->pin_in_cap, in_bytes);
     if (rc) return rc;
+    if (ctx->pin_out_cap < out_bytes) ctx->pin_out_dev = nullptr;
     rc = grow_pinned(&ctx->pin_out, &ctx->pin_out_cap, out_bytes);
     if (rc) return rc;
     uint8_t *hL = ctx->pin_in, *hR = ctx->pin_in + pin * rows;
     uint8_t *dL, *dR, *dO;
     if (zero_copy) {
-        void *di = nullptr, *dout = nullptr;
-        HIPCHK(hipHostGetDevicePointer(&di, ctx->pin_in, 0));
-        HIPCHK(hipHostGetDevicePointer(&dout, ctx->pin_out, 0));
-        dL = (uint8_t *)di; dR = dL + pin * rows; dO = (uint8_t *)dout;
+        if (!ctx->pin_in_dev || !ctx->pin_out_dev) {
+            void *di = nullptr, *dout = nullptr;
+            HIPCHK(hipHostGetDevicePointer(&di, ctx->pin_in, 0));
+            HIPCHK(hipHostGetDevicePointer(&dout, ctx->pin_out, 0));
+            ctx->pin_in_dev = (uint8_t *)di; ctx->pin_out_dev = (uint8_t *)dout;
+        }
+        dL = ctx->pin_in_dev; dR = dL + pin * rows; dO = ctx->pin_out_dev;
     } else {
         rc = grow(&ctx->stage_in, &ctx->stage_in_cap, in_bytes);
         if (rc) return rc;

@@ -4,6 +4,7 @@
 // known answers that need no oracle (K1 identical images, K2 constant images, K5 zero frame):
 //   sadbm::getDisparity(MatView)  ==  sadbm_compute_multi (1 GPU through RCCL)  ==  sadbm_compute_multi (3 "devices" on GPU 0,
 //   peer-copy gather, pipelined sub-bands)  ==  sadbm_compute_multi_batch  ==  the streaming pipeline.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,8 +18,30 @@ static int fails = 0;
 static uint32_t rng = 2463534242u;
 static uint8_t rnd() { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; return (uint8_t)(rng >> 11); }
 
-int main()
+// `abi_consumer --latency`: the synchronous host call at the C boundary on the reference's own configuration
+// (384x288 BGR pair, winSize 7, DSR 30: SAD.cpp:9-11,65-66) and on larger frames -- no Python in the loop.
+static int latency()
 {
+    const int cases[][5] = {{384, 288, 3, 7, 30}, {1920, 1080, 1, 9, 64}, {1920, 1080, 3, 9, 64}, {3840, 2160, 1, 15, 128}, {3840, 2160, 3, 15, 128}};
+    for (const auto &c : cases) {
+        const int W = c[0], H = c[1], ch = c[2], win = c[3], D = c[4];
+        sadbm::Image L(H, W, ch), R(H, W, ch), out(H, W, 1);
+        for (size_t i = 0; i < L.pix.size(); ++i) { L.pix[i] = rnd(); R.pix[i] = rnd(); }
+        sadbm_image li{L.pix.data(), H, W, ch, (int64_t)W * ch}, ri{R.pix.data(), H, W, ch, (int64_t)W * ch};
+        sadbm_plane op{out.pix.data(), H, W, W};
+        for (int i = 0; i < 5; ++i) if (sadbm_get_disparity(&li, &ri, win, D, 0, &op)) { printf("FAIL: %s\n", sadbm_last_hip_error()); return 1; }
+        const int n = W > 2000 ? 50 : 300;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < n; ++i) sadbm_get_disparity(&li, &ri, win, D, 0, &op);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n;
+        printf("sadbm_get_disparity %4dx%4d x%d win %2d D %3d: %8.1f us per call\n", W, H, ch, win, D, us);
+    }
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && !strcmp(argv[1], "--latency")) return latency();
     const int H = 203, W = 517, win = 9, D = 48;
     sadbm::Image L(H, W, 3), R(H, W, 3);                        // BGR, as cv::imread hands the reference (SAD.cpp:65-66)
     for (size_t i = 0; i < L.pix.size(); ++i) L.pix[i] = rnd();

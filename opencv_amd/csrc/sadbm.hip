@@ -23,6 +23,8 @@
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <condition_variable>
+#include <functional>
 #include <immintrin.h>
 #include <mutex>
 #include <new>
@@ -203,6 +205,8 @@ struct sadbm_ctx {
     size_t stage_out_cap = 0;
     uint8_t *pin_in = nullptr, *pin_out = nullptr;   // pinned host staging of the host API (pageable -> device copies are ~20x slower)
     size_t pin_in_cap = 0, pin_out_cap = 0;
+    hipStream_t stream2 = nullptr, stream3 = nullptr;   // host API, large frames: D2H of finished row chunks / H2D of the next chunk (lazily created)
+    hipEvent_t chunk_ev[3 * 16] = {};      // per chunk: computed / copied back / uploaded
     uint8_t *pin_in_dev = nullptr, *pin_out_dev = nullptr;   // device addresses of the pinned buffers (zero-copy path), resolved when they grow
     double *taps = nullptr;                // filter taps of sadbm_filter2d_device (filters.hip), one buffer per context
     char last_kernel[64] = "none";
@@ -278,16 +282,90 @@ __attribute__((target("ssse3"))) void extract_ch0_ssse3(uint8_t *dst, const uint
     }
     for (; x < cols; ++x) dst[x] = src[(size_t)x * ch];
 }
+// AVX2 form for BGR: two 48-byte groups per step, each half of a 256-bit register doing what the SSSE3 form does.
+__attribute__((target("avx2"))) void extract_ch0_bgr_avx2(uint8_t *dst, const uint8_t *src, int cols)
+{
+    const __m128i m0 = _mm_setr_epi8(0, 3, 6, 9, 12, 15, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    const __m128i m1 = _mm_setr_epi8(-1, -1, -1, -1, -1, -1, 2, 5, 8, 11, 14, -1, -1, -1, -1, -1);
+    const __m128i m2 = _mm_setr_epi8(-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 1, 4, 7, 10, 13);
+    const __m256i M0 = _mm256_broadcastsi128_si256(m0), M1 = _mm256_broadcastsi128_si256(m1), M2 = _mm256_broadcastsi128_si256(m2);
+    int x = 0;
+    for (; x + 32 <= cols; x += 32) {
+        const uint8_t *p = src + 3 * x;
+        const __m256i a = _mm256_inserti128_si256(_mm256_castsi128_si256(_mm_loadu_si128((const __m128i *)p)), _mm_loadu_si128((const __m128i *)(p + 48)), 1);
+        const __m256i b = _mm256_inserti128_si256(_mm256_castsi128_si256(_mm_loadu_si128((const __m128i *)(p + 16))), _mm_loadu_si128((const __m128i *)(p + 64)), 1);
+        const __m256i c = _mm256_inserti128_si256(_mm256_castsi128_si256(_mm_loadu_si128((const __m128i *)(p + 32))), _mm_loadu_si128((const __m128i *)(p + 80)), 1);
+        _mm256_storeu_si256((__m256i *)(dst + x), _mm256_or_si256(_mm256_or_si256(_mm256_shuffle_epi8(a, M0), _mm256_shuffle_epi8(b, M1)), _mm256_shuffle_epi8(c, M2)));
+    }
+    if (x < cols) extract_ch0_ssse3(dst + x, src + 3 * (size_t)x, cols - x, 3);
+}
 void extract_ch0(uint8_t *dst, const uint8_t *src, int cols, int ch)
 {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2 && ch == 3) { extract_ch0_bgr_avx2(dst, src, cols); return; }
     static const bool ssse3 = __builtin_cpu_supports("ssse3");
     if (ssse3) { extract_ch0_ssse3(dst, src, cols, ch); return; }
     for (int x = 0; x < cols; ++x) dst[x] = src[(size_t)x * ch];
 }
 
+// A few persistent worker threads for the host-side row copies of the host API (one core copies ~10 GB/s; a 4K pair is
+// 25 MB per call, and starting threads per call costs more than copying 1 MB).  Created at the first large copy, never
+// destroyed (the workers sleep on a condition variable; the process's exit ends them).
+class CopyPool {
+public:
+    static CopyPool &get() { static CopyPool *p = new CopyPool(); return *p; }
+    int workers() const { return (int)th_.size(); }
+    // runs fn(part) for part = 0 .. parts-1: part 0 on the caller, the others on the workers; returns when all are done
+    void run(int parts, const std::function<void(int)> &fn)
+    {
+        if (parts <= 1 || th_.empty()) { for (int i = 0; i < parts; ++i) fn(i); return; }
+        std::unique_lock<std::mutex> call(call_mu_);             // one parallel copy at a time (callers on other threads queue up)
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &fn; next_ = 1; parts_ = parts; pending_ = parts - 1; ++gen_;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    CopyPool()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = hw > 1 ? (int)hw - 1 : 0;
+        if (n > 7) n = 7;
+        for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); });
+        for (auto &t : th_) t.detach();
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> g(mu_);
+        for (;;) {
+            cv_.wait(g, [&] { return gen_ != seen && fn_ && next_ < parts_; });
+            while (fn_ && next_ < parts_) {
+                const int part = next_++;
+                const std::function<void(int)> *f = fn_;
+                g.unlock();
+                (*f)(part);
+                g.lock();
+                if (--pending_ == 0) done_.notify_one();
+            }
+            seen = gen_;
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_, call_mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int next_ = 0, parts_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+};
+
 // Row-wise host copy between a caller's (pageable, strided) image and pinned staging; ch > 1: channel 0 of `rowb` pixels
-// instead of `rowb` bytes.  Large frames are split over a few threads: one core copies ~10 GB/s, which would otherwise
-// bound the host API (a 4K pair is 25 MB per call).
+// instead of `rowb` bytes.  Copies of 512 KB and more are split over the pool: one part per 128 KB, at most 8.
 void copy_rows(uint8_t *dst, int64_t dstep, const uint8_t *src, int64_t sstep, size_t rowb, int rows, int ch = 1)
 {
     auto body = [=](int y0, int y1) {
@@ -297,19 +375,14 @@ void copy_rows(uint8_t *dst, int64_t dstep, const uint8_t *src, int64_t sstep, s
         }
     };
     const size_t bytes = rowb * (size_t)rows * (size_t)ch;
-    unsigned hw = std::thread::hardware_concurrency();
-    int nt = bytes >= ((size_t)4 << 20) ? (int)(bytes >> 21) : 1;      // one thread per 2 MB, at most 8
-    if (nt > 8) nt = 8;
-    if (hw && nt > (int)hw) nt = (int)hw;
+    int nt = bytes >= ((size_t)1 << 19) ? (int)(bytes >> 17) : 1;
+    if (nt > 1) { const int w = CopyPool::get().workers() + 1; if (nt > w) nt = w; if (nt > 8) nt = 8; if (nt > rows) nt = rows; }
     if (nt <= 1) { body(0, rows); return; }
-    std::vector<std::thread> th;
     const int per = (rows + nt - 1) / nt;
-    for (int t = 1; t < nt; ++t) {
-        const int y0 = t * per, y1 = y0 + per < rows ? y0 + per : rows;
-        if (y0 < y1) th.emplace_back(body, y0, y1);
-    }
-    body(0, per < rows ? per : rows);
-    for (auto &t : th) t.join();
+    CopyPool::get().run(nt, [&](int part) {
+        const int y0 = part * per, y1 = y0 + per < rows ? y0 + per : rows;
+        if (y0 < y1) body(y0, y1);
+    });
 }
 
 int check_params(int rows, int cols, int channels, int win, int max_disp, uint32_t flags)
@@ -640,6 +713,9 @@ void sadbm_destroy(sadbm_ctx *c)
     if (c->pin_in) (void)hipHostFree(c->pin_in);
     if (c->pin_out) (void)hipHostFree(c->pin_out);
     if (c->xev) (void)hipEventDestroy(c->xev);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
+    for (hipEvent_t e : c->chunk_ev) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 3 * c->ev_cap; ++i) (void)hipEventDestroy(c->ev[i]);
     delete[] c->ev;
     if (g_tls.c == c) g_tls.c = nullptr;
@@ -863,14 +939,63 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
         dL = ctx->stage_in; dR = ctx->stage_in + pin * rows; dO = ctx->stage_out;
     }
     hipStream_t st = ctx->stream;
-    // caller's (pageable, strided) rows -> pinned staging (-> device: one copy for both images; frames of several MB
-    // are sent one by one so that the R rows are gathered while the L transfer runs)
-    const bool split = !zero_copy && in_bytes > ((size_t)8 << 20);
+    if (!zero_copy && in_bytes >= ((size_t)4 << 20)) {
+        // Large frames, in row chunks: while chunk j's rows are gathered into pinned memory (copy pool), chunk j-1 is on its
+        // way to the device, the rows it completed are matched, and finished rows travel back on a second stream and are
+        // copied out -- the call then costs little more than the host-side copies (a 4K pair: 25 MB of them).
+        int nch = (int)(in_bytes >> 21);                        // one chunk per 2 MB of input, 2 .. 8
+        nch = nch < 2 ? 2 : nch > 8 ? 8 : nch;
+        const int chunk = (rows + nch - 1) / nch;
+        if (!ctx->stream2) HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        if (!ctx->stream3) HIPCHK(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+        hipStream_t up = ctx->stream3;                          // uploads run on their own stream: chunk j+1 travels while chunk j is matched
+        for (int i = 0; i < 3 * 16; ++i)
+            if (!ctx->chunk_ev[i]) HIPCHK(hipEventCreateWithFlags(&ctx->chunk_ev[i], hipEventDisableTiming));
+        int done = 0, copied = 0;                               // output rows computed so far / chunks copied out so far
+        int first[16], last[16];                                // output rows [first, last) of chunk j's compute
+        auto copy_out = [&](int j) {
+            if (last[j] > first[j])
+                copy_rows(out->data + (int64_t)first[j] * out->step, out->step, ctx->pin_out + pout * (size_t)first[j], (int64_t)pout,
+                          (size_t)cols, last[j] - first[j]);
+        };
+        for (int j = 0; j < nch; ++j) {
+            const int y0 = j * chunk < rows ? j * chunk : rows, y1 = y0 + chunk < rows ? y0 + chunk : rows;
+            if (y1 > y0) {
+                copy_rows(hL + pin * (size_t)y0, (int64_t)pin, left->data + (int64_t)y0 * left->step, left->step, (size_t)cols, y1 - y0, ch);
+                HIPCHK(hipMemcpyAsync(dL + pin * (size_t)y0, hL + pin * (size_t)y0, pin * (size_t)(y1 - y0), hipMemcpyHostToDevice, up));
+                copy_rows(hR + pin * (size_t)y0, (int64_t)pin, right->data + (int64_t)y0 * right->step, right->step, (size_t)cols, y1 - y0, ch);
+                HIPCHK(hipMemcpyAsync(dR + pin * (size_t)y0, hR + pin * (size_t)y0, pin * (size_t)(y1 - y0), hipMemcpyHostToDevice, up));
+            }
+            HIPCHK(hipEventRecord(ctx->chunk_ev[32 + j], up));
+            HIPCHK(hipStreamWaitEvent(st, ctx->chunk_ev[32 + j], 0));
+            // output rows whose windows (win rows down, SAD.cpp:39) are on the device now; the last chunk closes the frame
+            int upto = j == nch - 1 ? rows : y1 - (win - 1);
+            if (upto < done) upto = done;
+            first[j] = done; last[j] = upto;
+            if (upto > done) {
+                rc = sadbm_compute_band_device(ctx, dL + pin * (size_t)done, (int64_t)pin, dR + pin * (size_t)done, (int64_t)pin, rows, done,
+                                               y1 - done, upto - done, cols, 1, win, max_disp, flags, dO + pout * (size_t)done, (int64_t)pout, st);
+                if (rc) { (void)hipStreamSynchronize(up); (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(ctx->stream2); return rc; }
+                HIPCHK(hipEventRecord(ctx->chunk_ev[2 * j], st));
+                HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->chunk_ev[2 * j], 0));
+                HIPCHK(hipMemcpyAsync(ctx->pin_out + pout * (size_t)done, dO + pout * (size_t)done, pout * (size_t)(upto - done),
+                                      hipMemcpyDeviceToHost, ctx->stream2));
+                done = upto;
+            }
+            HIPCHK(hipEventRecord(ctx->chunk_ev[2 * j + 1], ctx->stream2));
+            while (copied < j && hipEventQuery(ctx->chunk_ev[2 * copied + 1]) == hipSuccess) copy_out(copied++);   // whatever has arrived
+        }
+        for (; copied < nch; ++copied) {
+            HIPCHK(hipEventSynchronize(ctx->chunk_ev[2 * copied + 1]));
+            copy_out(copied);
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        return SADBM_OK;
+    }
+    // caller's (pageable, strided) rows -> pinned staging -> device, one copy for both images
     copy_rows(hL, (int64_t)pin, left->data, left->step, (size_t)cols, rows, ch);
-    if (split) HIPCHK(hipMemcpyAsync(dL, hL, pin * rows, hipMemcpyHostToDevice, st));
     copy_rows(hR, (int64_t)pin, right->data, right->step, (size_t)cols, rows, ch);
-    if (split) HIPCHK(hipMemcpyAsync(dR, hR, pin * rows, hipMemcpyHostToDevice, st));
-    else if (!zero_copy) HIPCHK(hipMemcpyAsync(dL, hL, in_bytes, hipMemcpyHostToDevice, st));
+    if (!zero_copy) HIPCHK(hipMemcpyAsync(dL, hL, in_bytes, hipMemcpyHostToDevice, st));
     rc = sadbm_compute_device(ctx, dL, (int64_t)pin, dR, (int64_t)pin, rows, cols, 1, win, max_disp, flags, dO, (int64_t)pout, st);
     if (rc) return rc;
     if (!zero_copy) HIPCHK(hipMemcpyAsync(ctx->pin_out, dO, out_bytes, hipMemcpyDeviceToHost, st));

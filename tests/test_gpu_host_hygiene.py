@@ -123,3 +123,41 @@ def test_host_api_zero_copy_and_staged_paths_agree(monkeypatch):
         assert np.array_equal(oa.get_disparity_host(L, R, 7, 30), exp), zc
         assert np.array_equal(oa.get_disparity_host(roi[0], roi[1], 7, 30), exp_roi), zc
         oa.thread_release()                                    # next round starts from a fresh thread context
+
+
+def test_host_api_large_frames_go_through_the_chunk_pipeline():
+    """Frames of 4 MB and more are uploaded, matched and fetched in row chunks (copy pool + two streams): whole-frame
+    equality on 4K grey / BGR, 1080p, a wide and short frame whose chunks are shorter than the window, a pitched ROI,
+    and two host threads at once."""
+    L, R = oracle.rds(3, 3840, 2160, 16, 96, 0)
+    exp = oracle.box(L, R, 15, 128)
+    assert np.array_equal(oa.get_disparity_host(L, R, 15, 128), exp)
+    L3 = np.ascontiguousarray(np.stack([L, R, L], -1))
+    R3 = np.ascontiguousarray(np.stack([R, L, R], -1))
+    assert np.array_equal(oa.get_disparity_host(L3, R3, 15, 128), exp)                    # channel 0 = the grey planes above
+    big = np.zeros((2300, 4000), np.uint8)
+    bigr = np.zeros((2300, 4000), np.uint8)
+    big[70:2230, 100:3940] = L
+    bigr[70:2230, 100:3940] = R
+    assert np.array_equal(oa.get_disparity_host(big[70:2230, 100:3940], bigr[70:2230, 100:3940], 15, 128), exp)   # row stride 4000
+    L2, R2 = oracle.rds(2, 1920, 1200, 8, 40, 0)
+    assert np.array_equal(oa.get_disparity_host(L2, R2, 9, 64), oracle.box(L2, R2, 9, 64))
+    Lw, Rw = noise_pair(8, 36, 60000, shift=7)                                            # 2 chunks of 18 rows, window 21
+    assert np.array_equal(oa.get_disparity_host(Lw, Rw, 21, 40), oracle.box(Lw, Rw, 21, 40))
+    assert np.array_equal(oa.get_disparity_host(Lw, Rw, 7, 256), oracle.box(Lw, Rw, 7, 256))
+    errs = []
+
+    def work(a, b, w, d, e):
+        try:
+            for _ in range(3):
+                if not np.array_equal(oa.get_disparity_host(a, b, w, d), e):
+                    errs.append("mismatch")
+        except Exception as ex:                                 # noqa: BLE001
+            errs.append(repr(ex))
+
+    th = [threading.Thread(target=work, args=(L, R, 15, 128, exp)), threading.Thread(target=work, args=(L3, R3, 15, 128, exp))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs[:3]

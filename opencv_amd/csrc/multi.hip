@@ -299,8 +299,8 @@ int sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_ima
         // on the comm streams, while the compute streams go on with sub-band s+1
         const size_t off = (size_t)s * sper * cols;
         int cnt_rows = sper; if (s * sper + cnt_rows > per) cnt_rows = per - s * sper;
+        if (cnt_rows <= 0) continue;                          // sub_bands * sper may overshoot the band
         const size_t cnt = (size_t)cnt_rows * cols;
-        if (cnt == 0) continue;
         if (!copy_gather) {
             MNCCL(m, m->rccl.GroupStart());
             for (int root = 0; root < n; ++root)

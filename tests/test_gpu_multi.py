@@ -11,7 +11,7 @@ from helpers import noise_pair
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("sub_bands", [1, 3])
+@pytest.mark.parametrize("sub_bands", [1, 3, 7, 50])
 def test_multi_rccl_one_rank(sub_bands):
     L, R = noise_pair(7, 211, 333, shift=6)
     m = oa.Multi(1)
@@ -24,7 +24,7 @@ def test_multi_rccl_one_rank(sub_bands):
 
 
 @pytest.mark.parametrize("n", [2, 3, 5, 8])
-@pytest.mark.parametrize("sub_bands", [1, 4])
+@pytest.mark.parametrize("sub_bands", [1, 4, 7])
 def test_multi_copy_gather_virtual_devices(n, sub_bands):
     """H not divisible by n, bands shorter than the window, empty last bands, BGR input."""
     m = oa.Multi(n, devices=[0] * n, multi_flags=oa.MULTI_COPY_GATHER)

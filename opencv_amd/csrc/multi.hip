@@ -116,9 +116,12 @@ int grow_host(uint8_t **p, size_t *cap, size_t need)
     return SADBM_OK;
 }
 
-void copy_rows(uint8_t *dst, size_t dstep, const uint8_t *src, int64_t sstep, size_t rowb, int rows)
+// host-side row copies: sadbm.hip's pool-parallel copy, which also gathers channel 0 of colour rows (ch > 1) so that only
+// the plane the matcher reads (SAD.cpp:19-20) is staged and uploaded
+extern "C" void sadbm_internal_copy_rows(uint8_t *dst, int64_t dstep, const uint8_t *src, int64_t sstep, size_t cols, int rows, int ch);
+void copy_rows(uint8_t *dst, size_t dstep, const uint8_t *src, int64_t sstep, size_t cols, int rows, int ch = 1)
 {
-    for (int y = 0; y < rows; ++y) memcpy(dst + (size_t)y * dstep, src + (int64_t)y * sstep, rowb);
+    sadbm_internal_copy_rows(dst, (int64_t)dstep, src, sstep, cols, rows, ch);
 }
 
 int check_pair(const sadbm_image *l, const sadbm_image *r, int win, int D)
@@ -251,7 +254,7 @@ int sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_ima
     const int per = (rows + n - 1) / n;                       // rows per band; the last band(s) may be short or empty
     if (sub_bands > per) sub_bands = per;
     const int sper = (per + sub_bands - 1) / sub_bands;       // rows per sub-band (same on every GPU: equal counts)
-    const size_t rowb = (size_t)cols * ch, pin = (rowb + 255) & ~(size_t)255;
+    const size_t pin = ((size_t)cols + 255) & ~(size_t)255;   // staged rows hold channel 0 only
     const size_t map_bytes = (size_t)n * per * cols;
 
     // 1. per GPU: band + halo rows -> pinned -> device; zero the band slot's padding rows (bands past the frame's end)
@@ -265,8 +268,8 @@ int sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_ima
         if ((rc = grow_host(&g.hin, &g.in_cap, 2 * pin * (size_t)(per + win)))) return rc;
         if ((rc = grow_dev(&g.din, &g.din_cap, 2 * pin * (size_t)(per + win)))) return rc;
         if (rin > 0) {
-            copy_rows(g.hin, pin, left->data + (int64_t)r0 * left->step, left->step, rowb, rin);
-            copy_rows(g.hin + pin * (size_t)rin, pin, right->data + (int64_t)r0 * right->step, right->step, rowb, rin);
+            copy_rows(g.hin, pin, left->data + (int64_t)r0 * left->step, left->step, (size_t)cols, rin, ch);
+            copy_rows(g.hin + pin * (size_t)rin, pin, right->data + (int64_t)r0 * right->step, right->step, (size_t)cols, rin, ch);
         }
     }
     // 2. H2D + band compute (sub-band by sub-band), each GPU on its own stream; nothing blocks the host
@@ -287,7 +290,7 @@ int sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_ima
             if (s1 > s0) {
                 int si1 = s1 + win - 1; if (si1 > rows) si1 = rows;
                 const uint8_t *bl = g.din + pin * (size_t)(s0 - r0), *br = g.din + pin * (size_t)rin + pin * (size_t)(s0 - r0);
-                rc = sadbm_compute_band_device(g.ctx, bl, (int64_t)pin, br, (int64_t)pin, rows, s0, si1 - s0, s1 - s0, cols, ch, win,
+                rc = sadbm_compute_band_device(g.ctx, bl, (int64_t)pin, br, (int64_t)pin, rows, s0, si1 - s0, s1 - s0, cols, 1, win,
                                                max_disp, flags, slot + (size_t)(s0 - r0) * cols, cols, g.st);
                 if (rc) return rc;
             }
@@ -396,7 +399,7 @@ int sadbm_compute_multi_batch(sadbm_multi *m, const sadbm_image *lefts, const sa
         if (rows > 0 && cols > 0 && !outs[p].data) return SADBM_E_NULL;
     }
     if (rows == 0 || cols == 0) return SADBM_OK;
-    const size_t rowb = (size_t)cols * ch, pin = (rowb + 255) & ~(size_t)255, pout = ((size_t)cols + 255) & ~(size_t)255;
+    const size_t pin = ((size_t)cols + 255) & ~(size_t)255, pout = pin;   // staged rows hold channel 0 only
     // pair p -> GPU p % n, slot p / n of that GPU's staging; one batched launch sequence per GPU, no collective
     for (int i = 0; i < n; ++i) {
         Gpu &g = m->g[i];
@@ -412,11 +415,11 @@ int sadbm_compute_multi_batch(sadbm_multi *m, const sadbm_image *lefts, const sa
         uint8_t *hL = g.hin, *hR = g.hin + pin * rows * (size_t)mine;
         for (int k = 0; k < mine; ++k) {
             const int p = i + k * n;
-            copy_rows(hL + pin * rows * (size_t)k, pin, lefts[p].data, lefts[p].step, rowb, rows);
-            copy_rows(hR + pin * rows * (size_t)k, pin, rights[p].data, rights[p].step, rowb, rows);
+            copy_rows(hL + pin * rows * (size_t)k, pin, lefts[p].data, lefts[p].step, (size_t)cols, rows, ch);
+            copy_rows(hR + pin * rows * (size_t)k, pin, rights[p].data, rights[p].step, (size_t)cols, rows, ch);
         }
         MHIP(hipMemcpyAsync(g.din, g.hin, in_need, hipMemcpyHostToDevice, g.st));
-        rc = sadbm_compute_batch_device(g.ctx, g.din, g.din + pin * rows * (size_t)mine, (int64_t)pin, (int64_t)(pin * rows), mine, rows, cols, ch,
+        rc = sadbm_compute_batch_device(g.ctx, g.din, g.din + pin * rows * (size_t)mine, (int64_t)pin, (int64_t)(pin * rows), mine, rows, cols, 1,
                                         win, max_disp, flags, g.dmap, (int64_t)pout, (int64_t)(pout * rows), g.st);
         if (rc) return rc;
         MHIP(hipMemcpyAsync(g.hout, g.dmap, out_need, hipMemcpyDeviceToHost, g.st));

@@ -680,6 +680,11 @@ const char *sadbm_strerror(int code)
 
 const char *sadbm_last_hip_error(void) { return g_hip_err; }
 char *sadbm_internal_error_buffer(void) { return g_hip_err; }   // multi.hip writes its error text here (256 bytes)
+// multi.hip's host-side row copies: the same pool-parallel copy / channel-0 gather the host API uses
+void sadbm_internal_copy_rows(uint8_t *dst, int64_t dstep, const uint8_t *src, int64_t sstep, size_t cols, int rows, int ch)
+{
+    copy_rows(dst, dstep, src, sstep, cols, rows, ch);
+}
 
 int sadbm_create(int device, sadbm_ctx **out)
 {

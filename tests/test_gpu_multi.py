@@ -11,16 +11,23 @@ from helpers import noise_pair
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("sub_bands", [1, 3, 7, 50])
-def test_multi_rccl_one_rank(sub_bands):
-    L, R = noise_pair(7, 211, 333, shift=6)
+@pytest.fixture(scope="module")
+def rccl_multi():
+    """ONE single-rank RCCL communicator for the whole module (ncclCommInitAll starts proxy threads and a bootstrap)."""
     m = oa.Multi(1)
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("sub_bands", [1, 3, 7, 50])
+def test_multi_rccl_one_rank(rccl_multi, sub_bands):
+    L, R = noise_pair(7, 211, 333, shift=6)
+    m = rccl_multi
     for win, D in ((15, 48), (7, 30), (21, 200)):
         exp = oracle.box(L, R, win, D)
         got = m.compute(L, R, win, D, sub_bands=sub_bands)
         assert np.array_equal(got, exp), (win, D)
         assert np.array_equal(m.device_map(0, *L.shape).cpu().numpy(), exp)
-    m.close()
 
 
 @pytest.mark.parametrize("n", [2, 3, 5, 8])
@@ -39,14 +46,20 @@ def test_multi_copy_gather_virtual_devices(n, sub_bands):
     m.close()
 
 
-@pytest.mark.parametrize("n,flags", [(1, 0), (3, oa.MULTI_COPY_GATHER)])
-def test_multi_batch_round_robin(n, flags):
-    m = oa.Multi(n, devices=[0] * n, multi_flags=flags)
+@pytest.mark.parametrize("n", [1, 3])
+def test_multi_batch_round_robin(rccl_multi, n):
+    m = rccl_multi if n == 1 else oa.Multi(n, devices=[0] * n, multi_flags=oa.MULTI_COPY_GATHER)
     pairs = [oracle.rds(1000 + i, 310, 95, 5 + i, 20 + i, 0) for i in range(7)]
     outs = m.compute_batch([p[0] for p in pairs], [p[1] for p in pairs], 7, 64)
     for i, (L, R) in enumerate(pairs):
         assert np.array_equal(outs[i], oracle.box(L, R, 7, 64)), i
-    m.close()
+    L3 = [np.ascontiguousarray(np.stack([p[0], p[1], p[0]], -1)) for p in pairs]      # BGR: channel 0 gathered on the host
+    R3 = [np.ascontiguousarray(np.stack([p[1], p[0], p[1]], -1)) for p in pairs]
+    outs = m.compute_batch(L3, R3, 7, 64)
+    for i, (L, R) in enumerate(pairs):
+        assert np.array_equal(outs[i], oracle.box(L, R, 7, 64)), ("bgr", i)
+    if n != 1:
+        m.close()
 
 
 def test_multi_rejects_duplicate_devices_under_rccl():

@@ -6,7 +6,7 @@ import ctypes
 
 import numpy as np
 
-from .stereo import SadbmError, _check, _ctx_for, load_library
+from .stereo import SadbmError, _Image, _check, _ctx_for, load_library
 
 _bound = False
 
@@ -21,7 +21,11 @@ def _lib():
         L.sadbm_highpass_device.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, vp, i64, vp]
         L.sadbm_blend_device.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, dbl, vp, i64, vp]
         L.sadbm_ctx_device.argtypes = [vp]
-        for n in ("sadbm_gaussian_kernel", "sadbm_filter2d_device", "sadbm_highpass_device", "sadbm_blend_device", "sadbm_ctx_device"):
+        u8p, img = ctypes.c_void_p, ctypes.POINTER(_Image)
+        L.sadbm_gaus_filter_host.argtypes = [img, i32, i32, u8p, i64, u8p, i64]
+        L.sadbm_hybrid_image_host.argtypes = [img, img, i32, i32, i32, dbl, u8p, i64, u8p, i64, u8p, i64]
+        for n in ("sadbm_gaussian_kernel", "sadbm_filter2d_device", "sadbm_highpass_device", "sadbm_blend_device", "sadbm_ctx_device",
+                  "sadbm_gaus_filter_host", "sadbm_hybrid_image_host"):
             getattr(L, n).restype = i32
         _bound = True
     return L
@@ -102,3 +106,32 @@ def blend(mat1, mat2, alpha, out=None):
     with guard:
         _check(_lib().sadbm_blend_device(ctx.handle, ap, apitch, bp, bpitch, rows, cols, ch, ctypes.c_double(alpha), op, opitch, st))
     return out
+
+
+def _host_image(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    if a.ndim != 3:
+        raise SadbmError(-3, "images must be HxW or HxWxC")
+    return a, _Image(a.ctypes.data, a.shape[0], a.shape[1], a.shape[2], max(a.shape[1] * a.shape[2], 1))
+
+
+def gaus_filter_host(src, size=35, sigma=3):
+    """main() of gaus_filter.cpp:42-70 on a host image (numpy): (low_pass, high_pass).  Defaults = the program's #defines."""
+    a, ia = _host_image(src)
+    low, high = np.empty_like(a), np.empty_like(a)
+    step = max(a.shape[1] * a.shape[2], 1)
+    _check(_lib().sadbm_gaus_filter_host(ctypes.byref(ia), int(size), int(sigma), low.ctypes.data, step, high.ctypes.data, step))
+    return low.reshape(np.asarray(src).shape), high.reshape(np.asarray(src).shape)
+
+
+def hybrid_image_host(img1, img2, size=31, sigma=10, add=12, alpha=0.6):
+    """main() of hybrid_image.cpp:102-143 on host images: (low_pass of img1, high_pass of img2, hybrid)."""
+    a, ia = _host_image(img1)
+    b, ib = _host_image(img2)
+    low, high, mix = np.empty_like(a), np.empty_like(a), np.empty_like(a)
+    step = max(a.shape[1] * a.shape[2], 1)
+    _check(_lib().sadbm_hybrid_image_host(ctypes.byref(ia), ctypes.byref(ib), int(size), int(sigma), int(add), ctypes.c_double(alpha),
+                                          low.ctypes.data, step, high.ctypes.data, step, mix.ctypes.data, step))
+    return low, high, mix

@@ -109,3 +109,27 @@ def test_gaus_filter_and_hybrid_programs_end_to_end():
     big[10:90, 20:120] = _dev(dog[:80, :100])
     out = oa.filters.filter2D(big[10:90, 20:120], k)
     assert np.array_equal(out.cpu().numpy(), F.filter2d(dog[:80, :100].copy(), F.gaussian_kernel(31, 10)))
+
+
+@pytest.mark.gpu
+def test_host_level_filter_programs_match_the_oracle():
+    """sadbm_gaus_filter_host / sadbm_hybrid_image_host (what sadbm_cli --gaus / --hybrid call) on 1-, 3- and 4-channel
+    host images of odd sizes, against the oracle's definition of each step."""
+    rng = np.random.default_rng(11)
+    for shape in ((37, 53), (61, 47, 3), (40, 33, 4)):
+        a = rng.integers(0, 256, shape, dtype=np.uint8)
+        b = rng.integers(0, 256, shape, dtype=np.uint8)
+        low, high = oa.filters.gaus_filter_host(a)                       # 35 x 35, sigma 3 (gaus_filter.cpp:10-11)
+        r_low = F.filter2d(a, F.gaussian_kernel(35, 3))
+        assert np.array_equal(low, r_low), shape
+        assert np.array_equal(high, F.highpass(a, r_low, 0)), shape
+        if len(shape) == 3:
+            l2, h2, mix = oa.filters.hybrid_image_host(a, b)             # 31 x 31, sigma 10, += 12, alpha 0.6
+            k = F.gaussian_kernel(31, 10)
+            r_l = F.filter2d(a, k)
+            r_h = F.highpass(b, F.filter2d(b, k), 12)
+            assert np.array_equal(l2, r_l) and np.array_equal(h2, r_h), shape
+            assert np.array_equal(mix, F.blend(r_l, r_h, 0.6)), shape
+    with pytest.raises(oa.SadbmError) as e:
+        oa.filters.hybrid_image_host(np.zeros((8, 8), np.uint8), np.zeros((8, 8), np.uint8))   # add() indexes three channels
+    assert e.value.code == -2

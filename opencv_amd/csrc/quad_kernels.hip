@@ -432,14 +432,20 @@ __global__ void __launch_bounds__(256, (KC == 16 ? (WIN <= 16 ? 4 : 3) : (WIN <=
         }
     };
 
-    // Common geometry (256 threads, RW <= 128): every thread owns <= 1 L word and <= 2 R words of a row, so
-    // the next step's rows are fetched into registers BEFORE the compute of this step and written to the
-    // other LDS buffer after it -- the global-load latency hides behind ~600 VALU instructions.
-    const bool fastgeo = (nthr == 256) && (LW <= 256) && (RW <= 128);
+    // Common geometries: every thread owns <= 1 L word and <= 2 R words of a row, so the next step's rows are
+    // fetched into registers BEFORE the compute of this step and written to the other LDS buffer after it -- the
+    // global-load latency hides behind ~600 VALU instructions.  256 threads (RW <= 128): words sl and sl+64 of
+    // copy sg; 128 threads (RW <= 64, the half-width block of narrow or badly dividing frames): word sl of the
+    // copies sg and sg+2.
+    const bool geo256 = (nthr == 256) && (LW <= 256) && (RW <= 128);
+    const bool geo128 = (nthr == 128) && (LW <= 128) && (RW <= 64);
+    const bool fastgeo = geo256 || geo128;
+    const int pf_c1 = geo128 ? sg + 2 : sg, pf_w1 = geo128 ? sl : sl + 64;   // second R word: (copy, word)
     const int pf_lo = xb + 4 * tid;                           // L word of this thread
-    const int pf_r0 = xb - PADK + 4 * sl - sg, pf_r1 = pf_r0 + 4 * 64;   // R words sl and sl+64 of copy sg
+    const int pf_r0 = xb - PADK + 4 * sl - sg, pf_r1 = xb - PADK + 4 * pf_w1 - pf_c1;
+    const int pf_d0 = LW + sg * RW + sl, pf_d1 = LW + pf_c1 * RW + pf_w1;    // their places in a staged row
     const bool pf_lv = fastgeo && tid < LW && pf_lo <= xlim;
-    const bool pf_r0v = fastgeo && sl < RW && pf_r0 <= xlim, pf_r1v = fastgeo && sl + 64 < RW && pf_r1 <= xlim;
+    const bool pf_r0v = fastgeo && sl < RW && pf_r0 <= xlim, pf_r1v = fastgeo && pf_w1 < RW && pf_r1 <= xlim;
 
     const uint32_t *lp0 = rows + lofs, *rp0 = rows + rofs;
     const int nsteps = WIN - 1 + ny;
@@ -466,9 +472,8 @@ __global__ void __launch_bounds__(256, (KC == 16 ? (WIN <= 16 ? 4 : 3) : (WIN <=
             if (fastgeo) {
                 uint32_t *dst = rows + ((r + 1) & 1) * 2 * ROWW;
                 if (tid < LW) { dst[tid] = pl[0]; if (nold) dst[ROWW + tid] = pl[1]; }
-                uint32_t *d = dst + LW + sg * RW;
-                if (sl < RW) { d[sl] = pr0[0]; if (nold) d[ROWW + sl] = pr0[1]; }
-                if (sl + 64 < RW) { d[sl + 64] = pr1[0]; if (nold) d[ROWW + sl + 64] = pr1[1]; }
+                if (sl < RW) { dst[pf_d0] = pr0[0]; if (nold) dst[ROWW + pf_d0] = pr0[1]; }
+                if (pf_w1 < RW) { dst[pf_d1] = pr1[0]; if (nold) dst[ROWW + pf_d1] = pr1[1]; }
             } else {
                 stage(r + 1);
             }

@@ -404,6 +404,7 @@ struct EnvKnobs {
     int matcher = 0;             // SADBM_MATCHER    0 default, 1 strip, 2 quad
     int prep_bx = 0;             // SADBM_PREP_BX    block width of prep_plane_kernel (0 = choose)
     int kc = 0;                  // SADBM_KC         disparities per thread of the quad matcher (0 = choose)
+    int quad_half = -1;          // SADBM_QUAD_HALF  half-width (128-thread) blocks of the quad matcher: -1 choose, 0 never, 1 always
     long zc_bytes = 1 << 20;     // SADBM_ZEROCOPY_BYTES  host API: inputs up to this size are read by the GPU from pinned host memory
 };
 EnvKnobs read_env()
@@ -415,6 +416,7 @@ EnvKnobs read_env()
     if (const char *e = getenv("SADBM_MATCHER")) k.matcher = strcmp(e, "strip") == 0 ? 1 : strcmp(e, "quad") == 0 ? 2 : 0;
     k.prep_bx = geti("SADBM_PREP_BX", 0); if (k.prep_bx < 64 || k.prep_bx > 1024) k.prep_bx = 0; else k.prep_bx &= ~63;
     k.kc = geti("SADBM_KC", 0); if (k.kc != 8 && k.kc != 16) k.kc = 0;
+    k.quad_half = geti("SADBM_QUAD_HALF", -1); if (k.quad_half < 0 || k.quad_half > 1) k.quad_half = -1;
     if (const char *e = getenv("SADBM_ZEROCOPY_BYTES")) k.zc_bytes = atol(e);
     return k;
 }
@@ -617,11 +619,21 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         const int quads = (cols + 3) / 4;
         p.NQ = 256 / p.NCp;
         if (p.NQ > 16 && p.NQ > pow2ceil(quads)) p.NQ = pow2ceil(quads) < 16 ? 16 : pow2ceil(quads);
+        if (!use_global && p.NQ * p.NCp == 256 && p.NQ >= 32) {
+            // half-width blocks (128 threads) when the frame's column quads fill them better: 384 columns = 96
+            // quads = 3 x 32 exactly but 2 x 64 with a third of the threads idle; 1920 = 15 x 32 against 8 x 64.
+            const int h = p.NQ / 2;
+            const long full = (long)((quads + p.NQ - 1) / p.NQ) * p.NQ, half = (long)((quads + h - 1) / h) * h;
+            bool use_half = half * 100 < full * 97;
+            if (env().quad_half >= 0) use_half = env().quad_half != 0;
+            if (use_half) p.NQ = h;
+        }
         const int bx = (quads + p.NQ - 1) / p.NQ;
         // rows per block: long bands amortise the win-1 warm-up rows; shorten them until the grid
         // has a few blocks per CU.
         int TY = SADBM_TYMAX;
-        while (TY > 16 && (long)bx * ((nvalid + TY - 1) / TY) * n_pairs < SADBM_MINBLOCKS) TY >>= 1;
+        const long minblocks = (long)SADBM_MINBLOCKS * 256 / (p.NQ * p.NCp);   // counted in 256-thread blocks
+        while (TY > 16 && (long)bx * ((nvalid + TY - 1) / TY) * n_pairs < minblocks) TY >>= 1;
         p.TY = TY;
         dim3 g(bx, (nvalid + TY - 1) / TY, n_pairs);
         if (use_global) {

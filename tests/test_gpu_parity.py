@@ -71,6 +71,35 @@ def test_both_disparity_chunkings(kc, win, D, monkeypatch):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("half", ["0", "1", None])
+def test_quad_half_width_blocks(half, monkeypatch):
+    """The quad matcher runs 256-thread blocks or, for frames whose column quads fill them better (384 = 3 x 32 quads),
+    half-width 128-thread blocks with their own prefetch roles; force each (and the automatic choice) over widths on
+    both sides of the rule, single frames, batches, row bands, both chunkings and the border-heavy W < D case."""
+    if half is None:
+        monkeypatch.delenv("SADBM_QUAD_HALF", raising=False)
+    else:
+        monkeypatch.setenv("SADBM_QUAD_HALF", half)
+    oa.reload_env()
+    for (H, W) in ((45, 384), (33, 129), (40, 640), (30, 1920), (37, 333), (35, 100)):
+        L, R = noise_pair(7 * W + H, H, W, shift=6)
+        for win, D in ((7, 30), (9, 32), (5, 16), (3, 8), (11, 64), (15, 128), (21, 256), (25, 200), (7, 1)):
+            exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
+            got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_QUAD).cpu().numpy()
+            bad = np.argwhere(got != exp)
+            assert bad.size == 0, (half, H, W, win, D, len(bad), bad[:6])
+    # a batch of reference-sized frames (the case the half-width blocks are for) and a row band of a taller frame
+    Ls, Rs = zip(*[noise_pair(900 + i, 60, 384, shift=2 + i) for i in range(5)])
+    out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), 7, 30, oa.KERNEL_QUAD).cpu().numpy()
+    for i in range(5):
+        assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], 7, 30)), i
+    L, R = noise_pair(77, 150, 384, shift=4)
+    exp = oracle.box(L, R, 7, 30)
+    ctx = oa.Context(0)
+    band = oa.compute_band_device(dev(L[50:116]), dev(R[50:116]), 150, 50, 60, 7, 30, oa.KERNEL_QUAD, ctx=ctx).cpu().numpy()   # 60 rows + win-1 halo
+    assert np.array_equal(band, exp[50:110])
+
+
 @pytest.mark.parametrize("shape", [(9, 300), (300, 9), (40, 17), (8, 8), (7, 50), (50, 7), (1, 1), (33, 129)])
 def test_small_and_degenerate_shapes(shape):
     H, W = shape

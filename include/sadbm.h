@@ -84,7 +84,8 @@ int  sadbm_ctx_device(const sadbm_ctx *ctx);            /* the device the contex
 
 /* getDisparity(left, right) with explicit winSize / DSR (SAD.cpp:24, :9, :11).  Host buffers in, host
  * buffer out, synchronous.  Every byte of `out` (rows x cols of `left`) is written.  Uses a lazily
- * created thread-local context on device 0. */
+ * created thread-local context on the calling thread's current device (hipSetDevice; device 0 by default).
+ * No entry point of this library changes the calling thread's current device. */
 int sadbm_get_disparity(const sadbm_image *left, const sadbm_image *right, int win, int max_disp,
                         uint32_t flags, sadbm_plane *out);
 

@@ -163,7 +163,8 @@ int sadbm_filter2d_device(sadbm_ctx *ctx, const uint8_t *dSrc, int64_t src_pitch
     if (!dSrc || !dDst) return SADBM_E_NULL;
     if (src_pitch < (int64_t)cols * channels || dst_pitch < (int64_t)cols * channels) return SADBM_E_SIZE;
     const int dev = sadbm_ctx_device(ctx);
-    if (hipSetDevice(dev) != hipSuccess) return SADBM_E_HIP;
+    sadbm_detail::DeviceScope dscope(dev);
+    if (dscope.err != hipSuccess) return SADBM_E_HIP;
     hipStream_t st = (hipStream_t)stream;
     // taps: the context's 32 KB device buffer (one per context = one per stream, freed by sadbm_destroy), refilled on
     // the call's stream -- a later call on the same stream overwrites it only after this call's kernel has run
@@ -199,7 +200,8 @@ int sadbm_highpass_device(sadbm_ctx *ctx, const uint8_t *dSrc, int64_t src_pitch
     if (rows == 0 || rowbytes == 0) return SADBM_OK;
     if (!dSrc || !dLow || !dDst) return SADBM_E_NULL;
     if (src_pitch < rowbytes || low_pitch < rowbytes || dst_pitch < rowbytes) return SADBM_E_SIZE;
-    if (hipSetDevice(sadbm_ctx_device(ctx)) != hipSuccess) return SADBM_E_HIP;
+    sadbm_detail::DeviceScope dscope(sadbm_ctx_device(ctx));
+    if (dscope.err != hipSuccess) return SADBM_E_HIP;
     hipLaunchKernelGGL(highpass_kernel, dim3((rowbytes + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream, dSrc, src_pitch, dLow,
                        low_pitch, rowbytes, add, dDst, dst_pitch);
     return hipGetLastError() == hipSuccess ? SADBM_OK : SADBM_E_HIP;
@@ -215,7 +217,8 @@ int sadbm_blend_device(sadbm_ctx *ctx, const uint8_t *dM1, int64_t pitch1, const
     if (!dM1 || !dM2 || !dDst) return SADBM_E_NULL;
     const int64_t rowb = (int64_t)cols * channels;
     if (pitch1 < rowb || pitch2 < rowb || dst_pitch < rowb) return SADBM_E_SIZE;
-    if (hipSetDevice(sadbm_ctx_device(ctx)) != hipSuccess) return SADBM_E_HIP;
+    sadbm_detail::DeviceScope dscope(sadbm_ctx_device(ctx));
+    if (dscope.err != hipSuccess) return SADBM_E_HIP;
     hipLaunchKernelGGL(blend_kernel, dim3((unsigned)((rowb + 255) / 256), rows), dim3(256), 0, (hipStream_t)stream, dM1, pitch1, dM2, pitch2,
                        rows, cols, channels, alpha, dDst, dst_pitch);
     return hipGetLastError() == hipSuccess ? SADBM_OK : SADBM_E_HIP;
@@ -261,7 +264,10 @@ int sadbm_hybrid_image_host(const sadbm_image *img1, const sadbm_image *img2, in
     std::vector<double> taps((size_t)size * size);
     if ((rc = sadbm_gaussian_kernel(size, sigma, taps.data()))) return rc;
     sadbm_ctx *ctx = nullptr;
-    if ((rc = sadbm_create(0, &ctx))) return rc;
+    int dev = 0;                                               // everything below runs on the calling thread's current device
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    if ((rc = sadbm_create(dev, &ctx))) return rc;
+    sadbm_detail::DeviceScope dscope(dev);
     DevImages d;                                               // 0 img1, 1 img2, 2 low, 3 tmp, 4 high, 5 hybrid
     hipStream_t st = nullptr;                                  // the device's default stream: the copies below are synchronous
     auto fail = [&](int code) { sadbm_destroy(ctx); return code; };

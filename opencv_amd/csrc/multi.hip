@@ -20,7 +20,9 @@
 #include <new>
 #include <vector>
 
-#include "../../include/sadbm.h"
+#include <mutex>
+
+#include "sadbm_internal.hpp"
 
 namespace {
 
@@ -87,6 +89,7 @@ struct sadbm_multi {
     Rccl rccl;
     std::vector<Gpu> g;
     int map_rows = 0, map_cols = 0;                // geometry of the last sadbm_compute_multi
+    std::mutex mu;                                 // calls on one handle are serialised (they share the staging buffers)
 };
 
 namespace {
@@ -161,6 +164,7 @@ int sadbm_band_plan(int rows, int parts, int win, int index, int *row0, int *row
 void sadbm_multi_destroy(sadbm_multi *m)
 {
     if (!m) return;
+    sadbm_detail::DeviceKeeper keep;
     for (Gpu &g : m->g) {
         (void)hipSetDevice(g.device);
         if (g.st) (void)hipStreamSynchronize(g.st);
@@ -190,6 +194,7 @@ int sadbm_multi_create(int ngpu, const int *devices, uint32_t multi_flags, sadbm
     if (ngpu < 1 || ngpu > 64) return SADBM_E_PARAM;
     int ndev = 0;
     MHIP(hipGetDeviceCount(&ndev));
+    sadbm_detail::DeviceKeeper keep;
     std::vector<int> devs(ngpu);
     bool dup = false;
     for (int i = 0; i < ngpu; ++i) {
@@ -250,6 +255,8 @@ int sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_ima
     if (rows == 0 || cols == 0) return SADBM_OK;
     if (out && !out->data) return SADBM_E_NULL;
     if (sub_bands < 1) sub_bands = 1;
+    sadbm_detail::DeviceKeeper keep;
+    std::lock_guard<std::mutex> guard(m->mu);
     const bool copy_gather = (m->mflags & SADBM_MULTI_COPY_GATHER) != 0;
     const int per = (rows + n - 1) / n;                       // rows per band; the last band(s) may be short or empty
     if (sub_bands > per) sub_bands = per;
@@ -378,6 +385,7 @@ int sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_ima
 int sadbm_multi_device_map(sadbm_multi *m, int index, const uint8_t **dmap, int64_t *pitch)
 {
     if (!m || !dmap || !pitch) return SADBM_E_NULL;
+    std::lock_guard<std::mutex> guard(m->mu);
     if (index < 0 || index >= m->n || !m->g[index].dmap || m->map_rows == 0) return SADBM_E_PARAM;
     *dmap = m->g[index].dmap;
     *pitch = m->map_cols;
@@ -399,6 +407,8 @@ int sadbm_compute_multi_batch(sadbm_multi *m, const sadbm_image *lefts, const sa
         if (rows > 0 && cols > 0 && !outs[p].data) return SADBM_E_NULL;
     }
     if (rows == 0 || cols == 0) return SADBM_OK;
+    sadbm_detail::DeviceKeeper keep;
+    std::lock_guard<std::mutex> guard(m->mu);
     const size_t pin = ((size_t)cols + 255) & ~(size_t)255, pout = pin;   // staged rows hold channel 0 only
     // pair p -> GPU p % n, slot p / n of that GPU's staging; one batched launch sequence per GPU, no collective
     for (int i = 0; i < n; ++i) {

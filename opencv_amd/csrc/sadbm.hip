@@ -489,7 +489,8 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
                  hipStream_t st)
 {
     if (n_pairs <= 0 || rows_out <= 0 || cols <= 0) return SADBM_OK;
-    HIPCHK(hipSetDevice(ctx->device));
+    DeviceScope dscope(ctx->device);
+    HIPCHK(dscope.err);
     std::lock_guard<std::mutex> guard(ctx->mu);
     // The scratch planes are rewritten by every call: work queued on another stream by the previous call must be done
     // before this call's kernels touch them.  (If that stream has been destroyed meanwhile, wait for the whole device.)
@@ -705,7 +706,8 @@ int sadbm_create(int device, sadbm_ctx **out)
     int n = 0;
     HIPCHK(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) { snprintf(g_hip_err, sizeof(g_hip_err), "device %d of %d", device, n); return SADBM_E_HIP; }
-    HIPCHK(hipSetDevice(device));
+    DeviceScope dscope(device);
+    HIPCHK(dscope.err);
     sadbm_ctx *c = new (std::nothrow) sadbm_ctx();
     if (!c) return SADBM_E_ALLOC;
     c->device = device;
@@ -720,7 +722,7 @@ int sadbm_create(int device, sadbm_ctx **out)
 void sadbm_destroy(sadbm_ctx *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceScope dscope(c->device);
     // the scratch may still be read by kernels the caller queued on its own stream: hipFree waits for the device
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->planes && !c->planes_fixed) (void)hipFree(c->planes);
@@ -745,7 +747,8 @@ int sadbm_ctx_taps(sadbm_ctx *ctx, double **taps, int count)
 {
     if (!ctx || !taps) return SADBM_E_NULL;
     if (count < 1 || count > 4096) return SADBM_E_PARAM;
-    HIPCHK(hipSetDevice(ctx->device));
+    DeviceScope dscope(ctx->device);
+    HIPCHK(dscope.err);
     std::lock_guard<std::mutex> guard(ctx->mu);
     if (!ctx->taps) {
         hipError_t e = hipMalloc((void **)&ctx->taps, 4096 * sizeof(double));
@@ -763,7 +766,8 @@ int sadbm_profile_begin(sadbm_ctx *ctx, int max_launches)
 {
     if (!ctx) return SADBM_E_NULL;
     if (max_launches < 1 || max_launches > 65536) return SADBM_E_PARAM;
-    HIPCHK(hipSetDevice(ctx->device));
+    DeviceScope dscope(ctx->device);
+    HIPCHK(dscope.err);
     if (ctx->ev_cap < max_launches) {
         hipEvent_t *ne = new (std::nothrow) hipEvent_t[3 * (size_t)max_launches];
         if (!ne) return SADBM_E_ALLOC;
@@ -844,7 +848,8 @@ int static_scratch_for(int device, StaticDev **out)
     std::lock_guard<std::mutex> guard(g_static_mu);
     StaticDev &d = g_static_dev[device];
     if (!d.ready) {
-        HIPCHK(hipSetDevice(device));
+        DeviceScope dscope(device);
+        HIPCHK(dscope.err);
         void *ptr = nullptr;
         HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
         if (!ptr) { snprintf(g_hip_err, sizeof(g_hip_err), "hipGetSymbolAddress returned NULL"); return SADBM_E_HIP; }
@@ -925,7 +930,8 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
     if (!left->data || !right->data || !out->data) return SADBM_E_NULL;
     const size_t rowb = (size_t)cols * ch;
     if (left->step < (int64_t)rowb || right->step < (int64_t)rowb || out->step < cols) return SADBM_E_SIZE;
-    HIPCHK(hipSetDevice(ctx->device));
+    DeviceScope dscope(ctx->device);
+    HIPCHK(dscope.err);
     // colour inputs: only channel 0 is ever read (SAD.cpp:19-20) -- it is gathered while the rows are copied to pinned memory
     const size_t pin = ((size_t)cols + 255) & ~(size_t)255, pout = pin;
     const size_t in_bytes = 2 * pin * rows, out_bytes = pout * rows;
@@ -1024,8 +1030,13 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
 int sadbm_get_disparity(const sadbm_image *left, const sadbm_image *right, int win, int max_disp, uint32_t flags,
                         sadbm_plane *out)
 {
+    // on the calling thread's current device (hipSetDevice), as a HIP program expects; a thread that moves to another
+    // device gets a new context there
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    if (g_tls.c && g_tls.c->device != dev) sadbm_thread_release();
     if (!g_tls.c) {
-        int rc = sadbm_create(0, &g_tls.c);
+        int rc = sadbm_create(dev, &g_tls.c);
         if (rc) return rc;
     }
     return sadbm_get_disparity_ctx(g_tls.c, left, right, win, max_disp, flags, out);
@@ -1061,7 +1072,7 @@ extern "C" {
 void sadbm_pipeline_destroy(sadbm_pipeline *p)
 {
     if (!p) return;
-    (void)hipSetDevice(p->device);
+    DeviceScope dscope(p->device);
     for (int i = 0; i < p->depth && p->slots; ++i) {
         sadbm_pipeline::Slot &s = p->slots[i];
         if (s.ctx) { (void)hipStreamSynchronize(s.ctx->stream); }
@@ -1143,7 +1154,8 @@ int sadbm_pipeline_submit(sadbm_pipeline *p, const sadbm_image *left, const sadb
         copy_rows(s.hL, (int64_t)p->in_step, left->data, left->step, rowb, p->rows);
         copy_rows(s.hR, (int64_t)p->in_step, right->data, right->step, rowb, p->rows);
     }
-    HIPCHK(hipSetDevice(p->device));
+    DeviceScope dscope(p->device);
+    HIPCHK(dscope.err);
     hipStream_t st = s.ctx->stream;
     HIPCHK(hipMemcpy2DAsync(s.dL, p->in_step, s.hL, p->in_step, rowb, p->rows, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpy2DAsync(s.dR, p->in_step, s.hR, p->in_step, rowb, p->rows, hipMemcpyHostToDevice, st));

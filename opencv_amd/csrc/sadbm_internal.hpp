@@ -67,5 +67,30 @@ template <int... I> struct Seq {};
 template <int N, int... I> struct MakeSeq : MakeSeq<N - 1, N - 1, I...> {};
 template <int... I> struct MakeSeq<0, I...> { typedef Seq<I...> type; };
 
+// Makes `device` current for the enclosing scope and puts the caller's device back afterwards: an entry point of this
+// library never leaves another device current on the calling thread.
+struct DeviceScope {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) { err = hipSetDevice(device); changed = err == hipSuccess && prev >= 0; }
+    }
+    ~DeviceScope() { if (changed) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
+// For entry points that walk over several devices: remembers the caller's device and puts it back on exit.
+struct DeviceKeeper {
+    int prev = -1;
+    DeviceKeeper() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceKeeper() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceKeeper(const DeviceKeeper &) = delete;
+    DeviceKeeper &operator=(const DeviceKeeper &) = delete;
+};
+
 }  // namespace sadbm_detail
 #endif

@@ -13,8 +13,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
 for case in range(n):
     win = int(rng.integers(4, 26)) if rng.random() < 0.85 else int(rng.choice([1, 2, 3, 26, 29, 31]))
-    D = int(rng.choice([16, 30, 33, 48, 64, 65, 100, 128, 129, 192, 255, 256]))
-    W = int(rng.choice([int(rng.integers(300, 1300)), int(rng.integers(1300, 4200)), 1920, 1242, 2048, 640]))
+    D = int(rng.choice([8, 16, 24, 30, 32, 33, 48, 64, 65, 100, 128, 129, 192, 255, 256]))
+    W = int(rng.choice([int(rng.integers(300, 1300)), int(rng.integers(1300, 4200)), int(rng.integers(40, 300)), 1920, 1242, 2048, 640, 384, 450]))
     H = int(rng.integers(win + 2, 420))
     pairs = int(rng.choice([1, 2, 3, 5, 9]))
     flags = int(rng.choice([0, 0, oa.KERNEL_STRIP, oa.KERNEL_QUAD])) | int(rng.choice([0, oa.RAW_LOC]))
@@ -23,7 +23,7 @@ for case in range(n):
         g = np.random.default_rng(1000 * case + i)
         L = g.integers(0, 256, (H, W), dtype=np.uint8)
         R = g.integers(0, 256, (H, W), dtype=np.uint8)
-        sh = int(g.integers(1, min(D, W // 2)))
+        sh = int(g.integers(1, max(2, min(D, W // 2))))
         R[:, :W - sh] = L[:, sh:]
         if case % 5 == 4:
             L = np.where(L & 0x80, 255, 0).astype(np.uint8); R = np.where(R & 0x80, 255, 0).astype(np.uint8)

@@ -213,7 +213,7 @@ struct sadbm_ctx {
     int cus = 256;                         // compute units of the device (grid shaping)
     // Calls on one context are serialised (mu) and ordered: the scratch planes are rewritten by every call, so when the
     // caller's stream changes the new stream first waits for the work the previous one still holds (xev).
-    std::mutex mu;
+    std::recursive_mutex mu;      // serialises calls on this context; recursive: the host call holds it across its device calls
     hipStream_t last_stream = nullptr;
     bool has_last = false;
     hipEvent_t xev = nullptr;
@@ -491,7 +491,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     if (n_pairs <= 0 || rows_out <= 0 || cols <= 0) return SADBM_OK;
     DeviceScope dscope(ctx->device);
     HIPCHK(dscope.err);
-    std::lock_guard<std::mutex> guard(ctx->mu);
+    std::lock_guard<std::recursive_mutex> guard(ctx->mu);
     // The scratch planes are rewritten by every call: work queued on another stream by the previous call must be done
     // before this call's kernels touch them.  (If that stream has been destroyed meanwhile, wait for the whole device.)
     if (ctx->has_last && ctx->last_stream != st) {
@@ -749,7 +749,7 @@ int sadbm_ctx_taps(sadbm_ctx *ctx, double **taps, int count)
     if (count < 1 || count > 4096) return SADBM_E_PARAM;
     DeviceScope dscope(ctx->device);
     HIPCHK(dscope.err);
-    std::lock_guard<std::mutex> guard(ctx->mu);
+    std::lock_guard<std::recursive_mutex> guard(ctx->mu);
     if (!ctx->taps) {
         hipError_t e = hipMalloc((void **)&ctx->taps, 4096 * sizeof(double));
         if (e != hipSuccess) { ctx->taps = nullptr; hip_fail(e, "hipMalloc"); return SADBM_E_ALLOC; }
@@ -932,6 +932,7 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
     if (left->step < (int64_t)rowb || right->step < (int64_t)rowb || out->step < cols) return SADBM_E_SIZE;
     DeviceScope dscope(ctx->device);
     HIPCHK(dscope.err);
+    std::lock_guard<std::recursive_mutex> guard(ctx->mu);                    // the pinned / device staging buffers belong to the context
     // colour inputs: only channel 0 is ever read (SAD.cpp:19-20) -- it is gathered while the rows are copied to pinned memory
     const size_t pin = ((size_t)cols + 255) & ~(size_t)255, pout = pin;
     const size_t in_bytes = 2 * pin * rows, out_bytes = pout * rows;

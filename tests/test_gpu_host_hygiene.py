@@ -161,3 +161,32 @@ def test_host_api_large_frames_go_through_the_chunk_pipeline():
     for t in th:
         t.join()
     assert not errs, errs[:3]
+
+
+def test_host_calls_of_several_threads_on_one_context_are_serialised():
+    """sadbm_get_disparity_ctx stages through buffers that belong to the context: threads that share one context (instead
+    of using their own thread-local ones) must still each get their own frame's result -- small (zero-copy), medium
+    (staged) and large (chunk pipeline) frames mixed."""
+    ctx = oa.Context(0)
+    jobs = []
+    for i, (H, W, win, D) in enumerate([(120, 384, 7, 30), (130, 384, 7, 30), (700, 1400, 9, 64), (710, 1400, 9, 64), (1300, 3000, 15, 128),
+                                        (1310, 3000, 15, 128)]):
+        L, R = noise_pair(4000 + i, H, W, shift=3 + i)
+        jobs.append((L, R, win, D, oracle.box(L, R, win, D)))
+    errs = []
+
+    def work(job):
+        L, R, win, D, exp = job
+        try:
+            for _ in range(4):
+                if not np.array_equal(oa.get_disparity_host(L, R, win, D, ctx=ctx), exp):
+                    errs.append(("mismatch", L.shape))
+        except Exception as ex:                                 # noqa: BLE001
+            errs.append(repr(ex))
+
+    th = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs

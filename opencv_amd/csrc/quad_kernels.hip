@@ -29,6 +29,12 @@ template <int WIN>
 struct Geo {
     static constexpr int NW = (WIN + 6) / 4;                 // words covering bytes [0, WIN+3) of a quad's span
     static constexpr bool HI16 = (WIN * WIN * 255 <= 65535); // cost fits the high half of the key
+    // Slots that never compete (k > column, SAD.cpp:44; k >= D) are fixed per thread for the whole march, so where the
+    // cost field has a spare top bit they start from a "poisoned" running sum that no valid cost reaches -- the running
+    // add/subtract carries the offset along and the argmin needs no per-slot conditions.  (16-bit costs: windows up to
+    // 11x11; 32-bit costs: always.)
+    static constexpr bool POISON = HI16 ? (WIN * WIN * 255 < 32768) : true;
+    static constexpr uint32_t POISON_VALUE = HI16 ? 0x80000000u : 0x00800000u;
     // bytes of word j that fall into the window of column x0+a, i.e. positions [a, a+WIN)
     static constexpr uint32_t mask(int j, int a)
     {
@@ -245,7 +251,10 @@ __global__ void __launch_bounds__(256, SADBM_WPE) sad_quad_kernel(Params p)
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) C[kk][a] = G::HI16 ? (uint32_t)(k0 + kk) : 0u;
+        for (int a = 0; a < 4; ++a) {
+            C[kk][a] = G::HI16 ? (uint32_t)(k0 + kk) : 0u;
+            if (G::POISON && kk > min(kmaxrel0 + a, dlim)) C[kk][a] |= G::POISON_VALUE;
+        }
 
     const int nsteps = WIN - 1 + ny;
     for (int r = 0; r < nsteps; ++r) {
@@ -265,7 +274,7 @@ __global__ void __launch_bounds__(256, SADBM_WPE) sad_quad_kernel(Params p)
         // ---- emit output row y ----
         const int y = yb + r - (WIN - 1);
         uint32_t best[4] = {KEY_MAX, KEY_MAX, KEY_MAX, KEY_MAX};
-        if (active) chunk_min<WIN, KC>(C, k0, kmaxrel0, dlim, slow, best);
+        if (active) chunk_min<WIN, KC>(C, k0, kmaxrel0, dlim, G::POISON ? false : slow, best);
         if (p.NCp > 1) {
             const int par = r & 1;
             if (c > 0) merge[par][tid] = make_uint4(best[0], best[1], best[2], best[3]);
@@ -395,7 +404,10 @@ __global__ void __launch_bounds__(256, (KC == 16 ? (WIN <= 16 ? 4 : 3) : (WIN <=
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) C[kk][a] = G::HI16 ? (uint32_t)(k0 + kk) : 0u;
+        for (int a = 0; a < 4; ++a) {
+            C[kk][a] = G::HI16 ? (uint32_t)(k0 + kk) : 0u;
+            if (G::POISON && kk > min(kmaxrel0 + a, dlim)) C[kk][a] |= G::POISON_VALUE;
+        }
 
     // Staging roles (no per-element index arithmetic): thread group g (64 threads, or the whole block when
     // it is smaller) copies shifted R copy g, g+ng, ...; every thread helps with the L segment.
@@ -482,7 +494,7 @@ __global__ void __launch_bounds__(256, (KC == 16 ? (WIN <= 16 ? 4 : 3) : (WIN <=
         uint32_t best[4] = {KEY_MAX, KEY_MAX, KEY_MAX, KEY_MAX};
         const int par = r & 1;
         if (emit) {
-            if (active) chunk_min<WIN, KC>(C, k0, kmaxrel0, dlim, slow, best);
+            if (active) chunk_min<WIN, KC>(C, k0, kmaxrel0, dlim, G::POISON ? false : slow, best);
             if (c > 0) merge[par * 256 + tid] = make_uint4(best[0], best[1], best[2], best[3]);
         }
         __syncthreads();

@@ -625,7 +625,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
             // quads = 3 x 32 exactly but 2 x 64 with a third of the threads idle; 1920 = 15 x 32 against 8 x 64.
             const int h = p.NQ / 2;
             const long full = (long)((quads + p.NQ - 1) / p.NQ) * p.NQ, half = (long)((quads + h - 1) / h) * h;
-            bool use_half = half * 100 < full * 97;
+            bool use_half = half * 100 < full * 92;     // a half-width slot costs 7-11 % more (profiles/r02b_quad_half_width_blocks.txt)
             if (env().quad_half >= 0) use_half = env().quad_half != 0;
             if (use_half) p.NQ = h;
         }

@@ -456,6 +456,10 @@ __global__ void __launch_bounds__(256, (KC == 16 ? (WIN <= 16 ? 4 : 3) : (WIN <=
     const int pf_lo = xb + 4 * tid;                           // L word of this thread
     const int pf_r0 = xb - PADK + 4 * sl - sg, pf_r1 = xb - PADK + 4 * pf_w1 - pf_c1;
     const int pf_d0 = LW + sg * RW + sl, pf_d1 = LW + pf_c1 * RW + pf_w1;    // their places in a staged row
+    // the padded planes of this pair from their first byte (p.L / p.R point PADL bytes into row 0); a plane is < 2 GB
+    const auto rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(L) - PADL, 0, 0x7fffffff, 0x00020000);
+    const auto rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(R) - PADL, 0, 0x7fffffff, 0x00020000);
+    const uint32_t uo_l = (uint32_t)(pf_lo + PADL), uo_r0 = (uint32_t)(pf_r0 + PADL), uo_r1 = (uint32_t)(pf_r1 + PADL);   // >= 0: PADK + 3 <= PADL
     const bool pf_lv = fastgeo && tid < LW && pf_lo <= xlim;
     const bool pf_r0v = fastgeo && sl < RW && pf_r0 <= xlim, pf_r1v = fastgeo && pf_w1 < RW && pf_r1 <= xlim;
 
@@ -469,11 +473,12 @@ __global__ void __launch_bounds__(256, (KC == 16 ? (WIN <= 16 ? 4 : 3) : (WIN <=
         const bool nold = r + 1 >= WIN;                       // step r+1 has a leaving row
         uint32_t pl[2] = {0, 0}, pr0[2] = {0, 0}, pr1[2] = {0, 0};
         if (fastgeo && more) {
-            const uint8_t *Ln = L + (int64_t)(yb + r + 1) * p.pitch, *Rn = R + (int64_t)(yb + r + 1) * p.pitch;
-            const int64_t back = (int64_t)WIN * p.pitch;
-            if (pf_lv) { pl[0] = *(const uint32_t *)(Ln + pf_lo); if (nold) pl[1] = *(const uint32_t *)(Ln + pf_lo - back); }
-            if (pf_r0v) { pr0[0] = *(const u32u *)(Rn + pf_r0); if (nold) pr0[1] = *(const u32u *)(Rn + pf_r0 - back); }
-            if (pf_r1v) { pr1[0] = *(const u32u *)(Rn + pf_r1); if (nold) pr1[1] = *(const u32u *)(Rn + pf_r1 - back); }
+            // buffer loads: one descriptor per padded plane (block-uniform), the row as the scalar offset, the lane's
+            // column as an unsigned 32-bit offset -- no 64-bit VALU address arithmetic in the loop
+            const uint32_t rown = (uint32_t)((yb + r + 1) * p.pitch), rowo = rown - (uint32_t)(WIN * p.pitch);
+            if (pf_lv) { pl[0] = __builtin_amdgcn_raw_buffer_load_b32(rsL, uo_l, rown, 0); if (nold) pl[1] = __builtin_amdgcn_raw_buffer_load_b32(rsL, uo_l, rowo, 0); }
+            if (pf_r0v) { pr0[0] = __builtin_amdgcn_raw_buffer_load_b32(rsR, uo_r0, rown, 0); if (nold) pr0[1] = __builtin_amdgcn_raw_buffer_load_b32(rsR, uo_r0, rowo, 0); }
+            if (pf_r1v) { pr1[0] = __builtin_amdgcn_raw_buffer_load_b32(rsR, uo_r1, rown, 0); if (nold) pr1[1] = __builtin_amdgcn_raw_buffer_load_b32(rsR, uo_r1, rowo, 0); }
         }
         if (active) {
             // per-thread LDS pointers: one VGPR base per image, small immediate offsets per word

@@ -478,7 +478,9 @@ bool strip_is_default(int win, int D, int cols, int rows, int n_pairs)
 {
     if (win < 4) return false;
     if (D > 32) return true;
-    return (long)n_pairs * rows * cols <= 700000L;
+    // (tools/small_jobs.py, profiles/r02b_small_jobs_strip_vs_quad.txt: crossover 0.9-1.2 Mpixel at D = 30/32; at D <= 16 the
+    // quad matcher's blocks span 512 columns and a small job has too few of them: crossover ~2.5 Mpixel)
+    return (long)n_pairs * rows * cols <= (D <= 16 ? 2500000L : 900000L);
 }
 
 // The whole device pipeline for n_pairs frames (or one band).  Input rows available: rows_in; output

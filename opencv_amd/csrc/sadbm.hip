@@ -440,7 +440,7 @@ int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG, int n_cus)
         const long full = blocks / slots, rem = blocks - full * slots;
         double rounds = (double)full;
         if (rem > 0) rounds += (per_cu >= 2 && rem <= slots / 2) ? 0.65 : 1.0;
-        const double cost = (rounds + 0.4) * (ty + win - 1);   // +0.4: finer grids balance better (measured, tools/dbg/ty.sh)
+        const double cost = (rounds + 0.4) * (ty + win - 1);   // +0.4: finer grids balance better (measured with SADBM_STRIP_TY sweeps, profiles/r01*)
         if (cost < best) { best = cost; best_ty = ty; }
     }
     return best_ty;
@@ -559,7 +559,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     // block width: the multiple of 64 threads that wastes the fewest lanes over a row of pitch/16 chunks (4K: 264 chunks -> 320)
     const int cpr = pitch / 16;
     int pbx = 256; long pwaste = 1L << 60;
-    for (int b = 128; b <= 512; b += 64) {                     // measured (tools/dbg/prepbx.sh): 64-thread blocks are slow, ties -> larger
+    for (int b = 128; b <= 512; b += 64) {                     // measured (SADBM_PREP_BX sweep): 64-thread blocks are slow, ties -> larger
         const long w = (long)((cpr + b - 1) / b) * b - cpr;
         if (w <= pwaste) { pwaste = w; pbx = b; }
     }

@@ -58,8 +58,12 @@ def disparity_row_bands(left_band, right_band, frame_rows, win, max_disp, rank, 
         full = torch.empty((world * per, cols), dtype=torch.uint8, device=left_band.device)
         dist.all_gather_into_tensor(full, send, group=group)
         return full[:frame_rows]
-    # overlap needs a backend whose collectives run beside the compute stream (RCCL); elsewhere each piece is waited for at once
-    overlap = dist.get_backend(group) == "nccl" or not left_band.is_cuda
+    # overlap needs a backend whose collectives run beside the compute stream (RCCL).  Any other backend with device
+    # tensors (gloo rehearsals on a GPU box) exchanges each piece through host memory and waits for it at once: gloo's
+    # own device-tensor path hung on some piece sizes (tools/gloo_bands_check.py).
+    backend = dist.get_backend(group)
+    overlap = backend == "nccl" or not left_band.is_cuda
+    via_host = left_band.is_cuda and backend != "nccl"
     root = dst is None or dst == rank
     full = torch.zeros((world * per, cols), dtype=torch.uint8, device=left_band.device) if root else None
     send = full[rank * per:(rank + 1) * per] if root else torch.zeros((per, cols), dtype=torch.uint8, device=left_band.device)
@@ -76,11 +80,21 @@ def disparity_row_bands(left_band, right_band, frame_rows, win, max_disp, rank, 
             compute_band(left_band[s0 - r0:i1 - r0], right_band[s0 - r0:i1 - r0], frame_rows, s0, s1 - s0, win, max_disp, flags,
                          out=send[p0:p0 + (s1 - s0)])
         piece = send[p0:p1]
+        outs = [full[r * per + p0:r * per + p1] for r in range(world)] if root else None   # contiguous row ranges of the map
+        if via_host:
+            hpiece = piece.cpu()
+            houts = [torch.empty_like(hpiece) for _ in range(world)] if root else None
+            if dst is None:
+                dist.all_gather(houts, hpiece, group=group)
+            else:
+                dist.gather(hpiece, houts, dst=dst, group=group)
+            if root:
+                for o, h in zip(outs, houts):
+                    o.copy_(h)
+            continue
         if dst is None:
-            outs = [full[r * per + p0:r * per + p1] for r in range(world)]     # contiguous row ranges of the map
             works.append(dist.all_gather(outs, piece, group=group, async_op=True))
         else:
-            outs = [full[r * per + p0:r * per + p1] for r in range(world)] if root else None
             works.append(dist.gather(piece, outs, dst=dst, group=group, async_op=True))
         if not overlap:
             works.pop().wait()

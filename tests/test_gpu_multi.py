@@ -66,3 +66,19 @@ def test_multi_rejects_duplicate_devices_under_rccl():
     with pytest.raises(oa.SadbmError) as e:
         oa.Multi(2, devices=[0, 0])
     assert e.value.code == -4
+
+
+def test_two_ranks_sharing_the_gpu_rehearse_the_piecewise_exchange():
+    """Two processes (gloo, both on GPU 0) run disparity_row_bands with 1/2/4/7 sub-bands, gathered to all and to rank 0
+    (tools/gloo_bands_check.py): every variant gives the same map.  Device tensors under a non-RCCL backend travel
+    through host memory -- gloo's own device path hung on some piece sizes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(root, "tools", "gloo_bands_check.py")], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("done") == 2, r.stdout[-2000:]

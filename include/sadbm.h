@@ -152,6 +152,7 @@ int  sadbm_pipeline_wait(sadbm_pipeline *p, int64_t ticket, const uint8_t **resu
  *                             NULL) receives the map from the first GPU; sadbm_multi_device_map gives each GPU's copy.
  *   sadbm_compute_multi_batch n_pairs independent pairs, pair n on GPU n % ngpu, no collective (batch data
  *                             parallelism).
+ * Calls on one sadbm_multi are serialised (they share its staging buffers); none changes the caller's current device.
  * SADBM_MULTI_COPY_GATHER: assemble the map with peer copies (hipMemcpyPeerAsync) instead of RCCL -- the same
  * interface without the collective; it also allows one device to be listed several times (rehearsal of the
  * partition on a single GPU). */

@@ -430,18 +430,24 @@ int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG, int n_cus)
     const long cus = n_cus, per_cu = 16 / NG, slots = cus * per_cu;   // 16 waves per CU at 128 VGPRs; a block is NG waves
     const long cols = (long)bx * n_pairs;
     double best = 1e30; int best_ty = nvalid < 128 ? (nvalid > 0 ? nvalid : 1) : 128;
-    for (long m = 1; m <= 24; ++m) {
-        long nby = slots * m / cols;
-        if (nby < 1) continue;
-        if (nby > nvalid) nby = nvalid;
-        const int ty = (int)((nvalid + nby - 1) / nby);
-        if (ty > 512) continue;
+    auto consider = [&](int ty) {
         const long rnby = (nvalid + ty - 1) / ty, blocks = cols * rnby;
         const long full = blocks / slots, rem = blocks - full * slots;
         double rounds = (double)full;
         if (rem > 0) rounds += (per_cu >= 2 && rem <= slots / 2) ? 0.65 : 1.0;
         const double cost = (rounds + 0.4) * (ty + win - 1);   // +0.4: finer grids balance better (measured with SADBM_STRIP_TY sweeps, profiles/r01*)
         if (cost < best) { best = cost; best_ty = ty; }
+    };
+    // short bands first: a job that cannot fill one round of slots has no "whole rounds" candidate below, and fewer,
+    // longer blocks then beat one row per block (profiles/r02b_small_frames_rows_per_block.txt)
+    for (int ty = 1; ty <= 64 && ty <= nvalid; ++ty) consider(ty);
+    for (long m = 1; m <= 24; ++m) {
+        long nby = slots * m / cols;
+        if (nby < 1) continue;
+        if (nby > nvalid) nby = nvalid;
+        const int ty = (int)((nvalid + nby - 1) / nby);
+        if (ty > 512) continue;
+        consider(ty);
     }
     return best_ty;
 }

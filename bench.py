@@ -292,7 +292,7 @@ def main():
                                "prep_kernel_ms": round(p1 / max(n1, 1), 4),
                                "value": round(W * H * D / (lat_ms * 1e-3) / 1e9, 1), "unit": "Gdisp-evals/s"}
             w2, h2, win2, d2, seed2, bg2, fg2, n2 = WORKLOADS["cfg2b_1080p_w9_d128"]
-            n2 = 32
+            n2 = 64
             fr = [synth.rds(seed2 + 7919 * i, w2, h2, bg2, fg2, 0) for i in range(n2)]
             l2 = torch.from_numpy(np.stack([f[0] for f in fr])).to(dev)
             r2 = torch.from_numpy(np.stack([f[1] for f in fr])).to(dev)

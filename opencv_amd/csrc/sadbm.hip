@@ -405,6 +405,8 @@ struct EnvKnobs {
     int prep_bx = 0;             // SADBM_PREP_BX    block width of prep_plane_kernel (0 = choose)
     int kc = 0;                  // SADBM_KC         disparities per thread of the quad matcher (0 = choose)
     int quad_half = -1;          // SADBM_QUAD_HALF  half-width (128-thread) blocks of the quad matcher: -1 choose, 0 never, 1 always
+    int otf = -1;                // SADBM_OTF        on-the-fly form of the strip matcher (strip_otf_kernels.hip): -1 choose, 0 never, 1 whenever D <= 64
+    int otf_ng = 0;              // SADBM_OTF_NG     its disparity groups per block: 0 choose (fewest that cover D), 1, 2 or 4
     long zc_bytes = 1 << 20;     // SADBM_ZEROCOPY_BYTES  host API: inputs up to this size are read by the GPU from pinned host memory
 };
 EnvKnobs read_env()
@@ -417,6 +419,8 @@ EnvKnobs read_env()
     k.prep_bx = geti("SADBM_PREP_BX", 0); if (k.prep_bx < 64 || k.prep_bx > 1024) k.prep_bx = 0; else k.prep_bx &= ~63;
     k.kc = geti("SADBM_KC", 0); if (k.kc != 8 && k.kc != 16) k.kc = 0;
     k.quad_half = geti("SADBM_QUAD_HALF", -1); if (k.quad_half < 0 || k.quad_half > 1) k.quad_half = -1;
+    k.otf = geti("SADBM_OTF", -1); if (k.otf < 0 || k.otf > 1) k.otf = -1;
+    k.otf_ng = geti("SADBM_OTF_NG", 0); if (k.otf_ng != 1 && k.otf_ng != 2 && k.otf_ng != 4) k.otf_ng = 0;
     if (const char *e = getenv("SADBM_ZEROCOPY_BYTES")) k.zc_bytes = atol(e);
     return k;
 }
@@ -489,6 +493,16 @@ bool strip_is_default(int win, int D, int cols, int rows, int n_pairs)
     return (long)n_pairs * rows * cols <= (D <= 16 ? 2500000L : 900000L);
 }
 
+// The on-the-fly form of the strip matcher against the other two, from tools/otf_check.py sweep on MI355X
+// (profiles/r02e_otf_sweep*.txt: D = 4..64, windows 4..25, batches and single frames from 384x288 to 1080p): it is the
+// fastest in 580 of 640 cases, by 10-45 %; the exceptions are 4-wide windows from 17 disparities up (quad matcher 2-16 %
+// faster) and a few single 1080p frames at D = 33..40 (quad matcher 0-7 % faster), which keep the old choice / are let go.
+bool otf_is_default(int win, int D, int cols, int rows, int n_pairs)
+{
+    (void)cols; (void)rows; (void)n_pairs;
+    return D <= 64 && (win >= 5 || D <= 16);
+}
+
 // The whole device pipeline for n_pairs frames (or one band).  Input rows available: rows_in; output
 // rows written: rows_out; output rows [0,nvalid) are computed, the rest zero-filled.
 int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_t *dR, int64_t pitchR,
@@ -527,10 +541,17 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
 
     // matcher choice: SADBM_KERNEL_STRIP / SADBM_KERNEL_QUAD force one; env SADBM_MATCHER=strip|quad overrides the default
     bool use_strip = false;
-    const int strip_ng = D <= 64 ? 4 : D <= 128 ? 8 : 16;    // disparity groups of 16 per block (multiple of 4)
+    int strip_ng = D <= 64 ? 4 : D <= 128 ? 8 : 16;          // disparity groups of 16 per block (multiple of 4)
     strip_kernel_t sk = (win <= MAXWIN && cols < 65000) ? pick_strip_kernel(win, strip::NS + strip_ng) : nullptr;
+    // short searches: the on-the-fly form (blocks of 1, 2 or 4 groups of 16 disparities, strip_otf_kernels.hip)
+    int otf_lds = 0;
+    int otf_ng = D <= 16 ? 1 : D <= 32 ? 2 : 4;
+    if (env().otf_ng > otf_ng) otf_ng = env().otf_ng;
+    strip_kernel_t sk_otf = (D <= 64 && win <= MAXWIN && cols < 65000 && env().otf != 0) ? pick_strip_otf_kernel(win, otf_ng, &otf_lds) : nullptr;
+    const bool use_otf = sk_otf != nullptr && (env().otf == 1 || otf_is_default(win, D, cols, nvalid, n_pairs));
+    if (use_otf) { sk = sk_otf; strip_ng = otf_ng; }
     if (sk && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL | SADBM_KERNEL_QUAD))) {
-        use_strip = (flags & SADBM_KERNEL_STRIP) != 0 || strip_is_default(win, D, cols, nvalid, n_pairs);
+        use_strip = (flags & SADBM_KERNEL_STRIP) != 0 || use_otf || strip_is_default(win, D, cols, nvalid, n_pairs);
         if (env().matcher && !(flags & SADBM_KERNEL_STRIP)) use_strip = env().matcher == 1;
     }
 
@@ -597,8 +618,8 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         q.TY = TY;
         const int NSL = strip::NS + q.NG;
         int PR = 0, ROWW = 0;
-        strip_geometry(win, NSL, &PR, &ROWW);
-        const size_t lds = (size_t)(4 * ROWW + 3 * 64 * PR + 2 * 4 * 64 + 64) * 4;
+        if (!use_otf) strip_geometry(win, NSL, &PR, &ROWW);
+        const size_t lds = use_otf ? (size_t)otf_lds : (size_t)(4 * ROWW + 3 * 64 * PR + 2 * 4 * 64 + 64) * 4;
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         q.nbx = bx; q.nby = (nvalid + TY - 1) / TY; q.ngroups = n_groups;
         q.FG = FG; q.Wp = Wp; q.npairs = n_pairs;
@@ -607,7 +628,8 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         if (nblocks > 0x7ffffff0L) return SADBM_E_SIZE;
         dim3 g((unsigned)((nblocks + 7) & ~7L));               // 1-D, XCD-aware order decoded in the kernel
         hipLaunchKernelGGL(sk, g, dim3(64 * q.NG), lds, st, q);
-        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_strip_kernel<%d>", win);
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), use_otf ? "sad_strip_otf_kernel<%d>" : "sad_strip_kernel<%d>", win);
+        if (use_otf) snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_strip_otf_kernel<%d,%d>", win, otf_ng);
         HIPCHK(hipGetLastError());
         if (prof) { HIPCHK(hipEventRecord(ev[2], st)); ctx->ev_n++; }
         return SADBM_OK;

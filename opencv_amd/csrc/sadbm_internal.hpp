@@ -60,6 +60,8 @@ quad_kernel_t pick_quad_kernel(int win);                 // sad_quad_kernel<win>
 quad_kernel_t pick_quad_lds_kernel(int win, int kc);     // sad_quad_lds_kernel<win, kc>, kc in {8, 16}
 // strip_kernels.hip: nslm = NS + (4, 8 or 16 disparity groups); nullptr where the window has no strip instantiation
 strip_kernel_t pick_strip_kernel(int win, int nslm);
+// strip_otf_kernels.hip: the on-the-fly form of the strip matcher, ng = 1, 2 or 4 disparity groups per block (64 ng threads); its dynamic LDS size
+strip_kernel_t pick_strip_otf_kernel(int win, int ng, int *lds_bytes);
 // host copies of the strip kernel's compile-time geometry: staging passes per row image, dwords per row image
 void strip_geometry(int win, int nsl, int *pr, int *roww);
 

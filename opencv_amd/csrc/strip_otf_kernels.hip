@@ -1,0 +1,312 @@
+// strip_otf_kernels.hip -- the strip matcher for short searches ("on-the-fly" form): blocks of NG = 1, 2 or 4 groups of 16
+// disparities (64, 128 or 256 threads).  Compiled once per NG (-DSADBM_OTF_PART_NG=1 / 2 / 4) so the builds run in parallel.
+//
+// Same arithmetic as getDisparity()/sub_kernel() of /root/reference/SAD.cpp:13-61 and the same work split, window
+// decomposition, running sums, key phase and finalisation as sad_strip_kernel (sad_strip.inc): a thread owns 16 columns x 4
+// disparities of one byte-alignment class.  What differs is where the packed leftover-byte ("E") operands come from.
+// sad_strip_kernel has them pre-packed in LDS (4 arrays for L, 16 for R): that row image is as large for 32 disparities
+// as for 64, and at 32 it leaves room for 2 waves per SIMD only.  Here the block stages just the plain rows (L once, R
+// at the four byte shifts: 1.6 KB per row image instead of 7.2) and every thread builds its E operands itself with
+// v_perm_b32 from the aligned words it has loaded for the whole-word SADs anyway: both runs of an E word lie inside one
+// aligned word each, and the 16 (quad, disparity) pairs of a thread need only 7 distinct R positions, so a row pass
+// costs 16 + 28 permutes on top of its 4*NV + 64 SADs.  A block = 16 strips x 16 NG disparities = 64 NG threads; the 4 NG
+// (class, group) combinations are dealt to the waves four at a time (combination q = 4 wave + kgl: group q mod NG, class
+// q / NG -- one wave of 4 classes at NG = 1, two waves of 2 classes x 2 groups at NG = 2, one class per wave at NG = 4); the
+// one or two staging units per lane and step are prefetched round the ADD and SUB passes.
+#include "sadbm_internal.hpp"
+
+#ifndef SADBM_OTF_PART_NG
+#error "compile with -DSADBM_OTF_PART_NG=1, 2 or 4"
+#endif
+
+namespace sadbm_detail {
+
+#include "sad_strip.inc"
+
+namespace strip {
+
+template <int WIN, int NG_>
+struct OG {
+    using G = SG<WIN>;
+    static constexpr int NG = NG_;                               // disparity groups of 16 per block
+    static constexpr int NSL = NS + NG, RPS = NSL + 2;           // R slots that carry strips / staged per shifted copy
+    // an E word from aligned words: low run = nl bytes from byte bl of word wl, high run = nh bytes from byte bh of word wh
+    // (word indices relative to the quad's first word)
+    static constexpr int wl(int a) { return G::nl(a) ? G::lo0(a) / 4 : G::hi0(a) / 4; }
+    static constexpr int bl(int a) { return G::lo0(a) % 4; }
+    static constexpr int wh(int a) { return G::nh(a) ? G::hi0(a) / 4 : wl(a); }
+    static constexpr int bh(int a) { return G::hi0(a) % 4; }
+    static constexpr uint32_t sel(int a)                         // v_perm_b32(S0 = word wh, S1 = word wl)
+    {
+        uint32_t s = 0; int n = 0;
+        for (int b = 0; b < G::nl(a); ++b) s |= (uint32_t)(bl(a) + b) << (8 * n++);
+        for (int b = 0; b < G::nh(a); ++b) s |= (uint32_t)(4 + bh(a) + b) << (8 * n++);
+        for (; n < 4; ++n) s |= 0x0cu << (8 * n);
+        return s;
+    }
+    static constexpr bool run_ok(int a) { return (G::nl(a) == 0 || bl(a) + G::nl(a) <= 4) && (G::nh(a) == 0 || bh(a) + G::nh(a) <= 4); }
+    static constexpr int wmax1(int a) { return G::ne(a) ? (wl(a) > wh(a) ? wl(a) : wh(a)) : 0; }
+    static constexpr int WMAX = G::imax(G::imax(wmax1(0), wmax1(1)), G::imax(wmax1(2), wmax1(3)));
+    static constexpr int NLW = G::imax(G::NV, 3 + WMAX + 1);     // L words a strip reads (index of quad 3 + WMAX)
+    static constexpr int NRW = NLW + 4;                          // R words: index (word - t + 4), t = 0..3
+    static constexpr int NLWP = (NLW + 3) & ~3, NRWP = (NRW + 3) & ~3;
+    // LDS row image (dwords): LP[4 (NS+2)] | RP[4][4 RPS]
+    static constexpr int NLP = 4 * (NS + 2), SRP = 4 * RPS, OFF_RP = NLP, ROWW = OFF_RP + 4 * SRP;
+    static constexpr int NUNITS = (NS + 2) + 4 * RPS;            // 16-byte staging units per row image
+    static constexpr int UPL = (NUNITS + 64 * NG - 1) / (64 * NG);   // units per lane
+    static constexpr bool ok = G::ok && run_ok(0) && run_ok(1) && run_ok(2) && run_ok(3) && NLWP <= 12 && NRWP <= 16 && UPL <= 2;
+};
+
+// One image row folded into the running sums of this thread (ADD: entering row, SUB: leaving row).
+//   pL: LP + 4*strip; pR: this thread's first R word in RP[c] (one slot below the slot of its (strip, group))
+template <int WIN, bool SUB>
+__device__ __forceinline__ void strip_pass_otf(const uint32_t *pL, const uint32_t *pR, uint32_t (&V)[4][SG<WIN>::NV], uint32_t (&E)[4][4][2])
+{
+    using G = SG<WIN>;
+    using O = OG<WIN, 2>;                                        // word geometry only: the same for every NG
+    constexpr int NV = G::NV;
+    uint32_t lw[O::NLWP], rw[O::NRWP];
+#pragma unroll
+    for (int nb = 0; nb < O::NLWP; nb += 4) lds128(pL + nb, &lw[nb]);
+#pragma unroll
+    for (int nb = 0; nb < O::NRWP; nb += 4) lds128(pR + nb, &rw[nb]);
+    // ---- V: whole words ----
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const uint32_t r = rw[n - t + 4];
+            if constexpr (!SUB) V[t][n] = G::HI16 ? __builtin_amdgcn_sad_hi_u8(lw[n], r, V[t][n]) : __builtin_amdgcn_sad_u8(lw[n], r, V[t][n]);
+            else V[t][n] -= G::HI16 ? __builtin_amdgcn_sad_hi_u8(lw[n], r, 0u) : __builtin_amdgcn_sad_u8(lw[n], r, 0u);
+        }
+    // ---- E: leftover bytes, packed here; two column offsets per register (a = 2p low half, 2p+1 high half) ----
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        constexpr int A0[2] = {0, 2}, A1[2] = {1, 3};
+        const int a0 = A0[p], a1 = A1[p];
+        uint32_t l0[4], l1[4], r0[7], r1[7];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            l0[i] = G::ne(a0) ? __builtin_amdgcn_perm(lw[i + O::wh(a0)], lw[i + O::wl(a0)], O::sel(a0)) : 0u;
+            l1[i] = G::ne(a1) ? __builtin_amdgcn_perm(lw[i + O::wh(a1)], lw[i + O::wl(a1)], O::sel(a1)) : 0u;
+        }
+#pragma unroll
+        for (int d = 0; d < 7; ++d) {                            // d = i - t + 3
+            r0[d] = G::ne(a0) ? __builtin_amdgcn_perm(rw[d + 1 + O::wh(a0)], rw[d + 1 + O::wl(a0)], O::sel(a0)) : 0u;
+            r1[d] = G::ne(a1) ? __builtin_amdgcn_perm(rw[d + 1 + O::wh(a1)], rw[d + 1 + O::wl(a1)], O::sel(a1)) : 0u;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t e = SUB ? 0u : E[t][i][p];
+                if (G::ne(a0) > 0) e = __builtin_amdgcn_sad_u8(l0[i], r0[i - t + 3], e);
+                if (G::ne(a1) > 0) e = __builtin_amdgcn_sad_hi_u8(l1[i], r1[i - t + 3], e);
+                if constexpr (!SUB) E[t][i][p] = e;
+                else E[t][i][p] -= e;
+            }
+    }
+}
+
+template <int WIN, int NG_>
+__global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
+{
+    using G = SG<WIN>;
+    using O = OG<WIN, NG_>;
+    constexpr int NV = G::NV;
+    constexpr int ROWW = O::ROWW;
+    constexpr int NG = O::NG;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int nwaves = NG, nthr = 64 * NG;
+    uint32_t *rows = smem;                                    // [2 buffers][2 slots][ROWW]
+    uint32_t *cells = smem + 4 * ROWW;                        // [2 parities][4 a][64 quads]
+    uint32_t *fxs = cells + 2 * 4 * 64;                       // [64] frame / column of each output quad of the block
+
+    // 1-D XCD-aware launch, as sad_strip_kernel
+    const int chunk = (int)(gridDim.x >> 3);
+    const int vb = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (vb >= p.nbx * p.nby * p.ngroups) return;              // grid padded to a multiple of 8 (block-uniform exit)
+    const int bxi = vb % p.nbx, tb = vb / p.nbx, byi = tb % p.nby, pz = tb / p.nby;
+    const int XB = bxi * XBW;
+    const int nf = min(p.FG, p.npairs - pz * p.FG);
+    if (XB >= (nf - 1) * p.Wp + p.W) return;                  // block-uniform
+    const int yb = byi * p.TY;
+    const int ny = min(p.TY, p.nvalid - yb);
+    const uint8_t *Lbase = p.Lrow0 + (int64_t)pz * p.pair_stride;
+    const int ocols = p.W - p.win;
+
+    for (int i = tid; i < 2 * 4 * 64; i += nthr) cells[i] = KEY_MAX;
+    if (tid < 64) {
+        const int xv = XB + 4 * tid, f = xv / p.Wp, xl = xv - f * p.Wp;
+        fxs[tid] = (f < nf) ? ((uint32_t)f << 16) | (uint32_t)xl : 0xFFFFu;
+    }
+
+    // ---- staging role of this lane: units tid (+ nthr) of every row image (16 bytes of LP, or of RP[c]) ----
+    constexpr int UPL = O::UPL;
+    uint32_t uoff[UPL]; int udst[UPL];
+#pragma unroll
+    for (int j = 0; j < UPL; ++j) {
+        const int u = tid + j * nthr;
+        uoff[j] = 0; udst[j] = -1;
+        if (u < NS + 2) {
+            uoff[j] = (uint32_t)(PADL + XB + 16 * u); udst[j] = 4 * u;
+        } else if (u < O::NUNITS) {
+            const int v = u - (NS + 2), c = v / O::RPS, slot = v - c * O::RPS;
+            uoff[j] = p.lr_delta + (uint32_t)(PADL + XB - c + 16 * (slot - NG)); udst[j] = O::OFF_RP + c * O::SRP + 4 * slot;
+        }
+    }
+    // row `row` of the plane -> row slot `slot` of buffer `buf`
+    struct Units { u32x4u w[UPL]; };
+    auto unit_load = [&](int row) -> Units {
+        Units q;
+#pragma unroll
+        for (int j = 0; j < UPL; ++j) {
+            q.w[j] = u32x4u{0, 0, 0, 0};
+            if (udst[j] >= 0) q.w[j] = *(const u32x4u *)(Lbase + (int64_t)row * p.pitch + uoff[j]);
+        }
+        return q;
+    };
+    auto unit_store = [&](const Units &q, int buf, int slot) {
+#pragma unroll
+        for (int j = 0; j < UPL; ++j)
+            if (udst[j] >= 0) *(uint4 *)(rows + (buf * 2 + slot) * ROWW + udst[j]) = make_uint4(q.w[j].x, q.w[j].y, q.w[j].z, q.w[j].w);
+    };
+
+    // ---- compute role ----
+    const int kgl = G::SWAPNET ? lane >> 4 : lane & 3;        // slot within the wave's four (group, class) combinations
+    const int sl = G::SWAPNET ? lane & 15 : lane >> 2;        // strip within the block
+    const int cq = 4 * wave + kgl;                            // (class, group) combination of this lane
+    const int g = cq % NG, c = cq / NG;                       // disparity group (16 k each) and byte-alignment class
+    const int kb = 16 * g + c;                                // k_t = kb + 4t
+    const int xv = XB + 16 * sl, fr = xv / p.Wp;
+    const int xs = xv - fr * p.Wp;
+    const bool active = (fr < nf) && (xs < ocols) && (kb < p.D) && (kb <= xs + 15);
+    const bool diag = active && (kb + 12 > xs);
+    const bool mask_d = __any(active && (kb + 12 >= p.D));
+    const bool any_diag = __any(diag);
+    const EmitCtx ec = {kb, c, diag, {false, kb + 4 >= p.D, kb + 8 >= p.D, kb + 12 >= p.D}};
+    const bool wave_active = __any(active);
+    const bool wave_full = __all(active);
+    const int sb = sl - g + NG;                               // R slot of (strip, group); reads start one slot lower
+    const uint32_t *tL = rows + 4 * sl;
+    const uint32_t *tR = rows + O::OFF_RP + c * O::SRP + 4 * (sb - 1);
+
+    uint32_t V[4][NV], E[4][4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) V[t][n] = G::HI16 ? (uint32_t)(kb + 4 * t) : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { E[t][i][0] = 0; E[t][i][1] = 0; }
+    }
+
+    unit_store(unit_load(yb), 0, 0);
+    __syncthreads();
+
+    const int nsteps = WIN - 1 + ny;
+    for (int r = 0; r < nsteps; ++r) {
+        const int bo = (r & 1) * 2 * ROWW;
+        const bool emit = r >= WIN - 1;                       // block-uniform
+        const int par = r & 1;
+        uint32_t *cell = cells + par * 256;
+        const bool more = r + 1 < nsteps, more_old = more && r + 1 >= WIN;
+
+        // finalise the previous output row (its atomics completed before the barrier that ended step r-1)
+        if (r >= WIN && wave == (r & (nwaves - 1)))
+            strip_finalize<WIN>(p, cells + (par ^ 1) * 256, pz * p.FG, fxs[lane], yb + r - WIN, lane, ocols, true);
+
+        // the rows of step r+1 are fetched into registers before the passes of step r and written to the other buffer after them
+        Units wn, wo;
+        if (more) wn = unit_load(yb + r + 1);
+        if (active) strip_pass_otf<WIN, false>(tL + bo, tR + bo, V, E);
+        if (more) unit_store(wn, (r + 1) & 1, 0);
+        if (more_old) wo = unit_load(yb + r + 1 - WIN);
+        if (active && r >= WIN) strip_pass_otf<WIN, true>(tL + bo + ROWW, tR + bo + ROWW, V, E);
+        if (more_old) unit_store(wo, (r + 1) & 1, 1);
+
+        if (emit && wave_active) {
+            uint32_t pub[4] = {KEY_MAX, KEY_MAX, KEY_MAX, KEY_MAX};
+            if (mask_d)          strip_emit<WIN, EM_MASK, false>(V, E, active, kgl, ec, pub);
+            else if (any_diag)   strip_emit<WIN, EM_DIAG, false>(V, E, active, kgl, ec, pub);
+            else if (!wave_full) strip_emit<WIN, EM_FAST, false>(V, E, active, kgl, ec, pub);
+            else                 strip_emit<WIN, EM_FAST, true>(V, E, active, kgl, ec, pub);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) atomicMin(&cell[a * 64 + lane], pub[a]);
+        }
+        __syncthreads();
+    }
+
+    // last output row
+    if (ny > 0 && wave == nwaves - 1)
+        strip_finalize<WIN>(p, cells + ((nsteps & 1) ^ 1) * 256, pz * p.FG, fxs[lane], yb + nsteps - WIN, lane, ocols, false);
+
+    // the zero frame below the computed rows (SAD.cpp:31,34), written by the blocks of the last band
+    if (byi == p.nby - 1) {
+        const uint32_t fx = fxs[lane];
+        const int x0 = (int)(fx & 0xFFFFu);
+        if (x0 < p.W) {
+            uint8_t *o = p.out + (int64_t)(pz * p.FG + (int)(fx >> 16)) * p.out_stride + x0;
+            for (int zr = p.nvalid + wave; zr < p.rows_out; zr += nwaves) {
+                uint8_t *q = o + (int64_t)zr * p.out_pitch;
+                if (p.dword_store && x0 + 3 < p.W) *(uint32_t *)q = 0u;
+                else
+                    for (int a = 0; a < 4 && x0 + a < p.W; ++a) q[a] = 0;
+            }
+        }
+    }
+}
+
+}  // namespace strip
+
+strip_kernel_t otf_part_1(int win, int *lds_bytes);
+strip_kernel_t otf_part_2(int win, int *lds_bytes);
+strip_kernel_t otf_part_4(int win, int *lds_bytes);
+
+namespace {
+constexpr int PNG = SADBM_OTF_PART_NG;
+template <int WIN>
+static strip_kernel_t otf_entry()
+{
+    if constexpr (WIN >= 4 && strip::SG<WIN>::ok && strip::OG<WIN, PNG>::ok) return strip::sad_strip_otf_kernel<WIN, PNG>;
+    else return nullptr;
+}
+template <int WIN>
+static int otf_lds_one()
+{
+    if constexpr (WIN >= 4 && strip::SG<WIN>::ok && strip::OG<WIN, PNG>::ok) return (4 * strip::OG<WIN, PNG>::ROWW + 2 * 4 * 64 + 64) * 4;
+    else return 0;
+}
+template <int... I>
+strip_kernel_t otf_table(int win, Seq<I...>)
+{
+    static const strip_kernel_t t[] = { otf_entry<I + 1>()... };
+    return t[win - 1];
+}
+template <int... I>
+int otf_lds_table(int win, Seq<I...>)
+{
+    static const int t[] = { otf_lds_one<I + 1>()... };
+    return t[win - 1];
+}
+}  // namespace
+
+#define SADBM_CAT2(a, b) a##b
+#define SADBM_CAT(a, b) SADBM_CAT2(a, b)
+strip_kernel_t SADBM_CAT(otf_part_, SADBM_OTF_PART_NG)(int win, int *lds_bytes)
+{
+    if (lds_bytes) *lds_bytes = otf_lds_table(win, MakeSeq<MAXWIN>::type());
+    return otf_table(win, MakeSeq<MAXWIN>::type());
+}
+
+#if SADBM_OTF_PART_NG == 2
+strip_kernel_t pick_strip_otf_kernel(int win, int ng, int *lds_bytes)
+{
+    if (win < 1 || win > MAXWIN) return nullptr;
+    return ng == 1 ? otf_part_1(win, lds_bytes) : ng == 2 ? otf_part_2(win, lds_bytes) : ng == 4 ? otf_part_4(win, lds_bytes) : nullptr;
+}
+#endif
+
+}  // namespace sadbm_detail

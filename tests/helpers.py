@@ -48,3 +48,11 @@ def noise_pair(seed, H, W, shift=None, binary=False, ch=1):
         L = np.where(L & 0x80, 255, 0).astype(np.uint8)
         R = np.where(R & 0x80, 255, 0).astype(np.uint8)
     return L, R
+
+
+def strip_kernel_name(win, D, staged=False):
+    """Which member of the strip family run_pipeline launches under KERNEL_STRIP (sadbm.hip, otf_is_default): the
+    on-the-fly form for searches of at most 64 disparities, unless SADBM_OTF=0 (`staged`)."""
+    if not staged and D <= 64 and (win >= 5 or D <= 16):
+        return "sad_strip_otf_kernel<%d,%d>" % (win, 1 if D <= 16 else 2 if D <= 32 else 4)
+    return "sad_strip_kernel<%d>" % win

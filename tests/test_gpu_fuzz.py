@@ -58,6 +58,6 @@ def test_very_wide_frame_and_many_tiny_frames():
     n = 700
     Ls, Rs = zip(*[noise_pair(900 + i, 11, 23, shift=2) for i in range(n)])
     out = oa.compute_batch_device(torch.from_numpy(np.stack(Ls)).cuda(), torch.from_numpy(np.stack(Rs)).cuda(), 4, 48, 0, ctx=ctx).cpu().numpy()
-    assert ctx.last_kernel() == "sad_strip_kernel<4>"
+    assert ctx.last_kernel() == "sad_strip_kernel<4>"            # 4-wide windows keep the staged form from 17 disparities up
     for i in range(n):
         assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], 4, 48)), i

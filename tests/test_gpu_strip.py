@@ -1,12 +1,24 @@
-"""GPU parity of the strip matcher (sad_strip_kernel, forced with KERNEL_STRIP) against the oracle, and of the
-default matcher choice against both forced kernels.  Bit-exact bar; calls go through the C ABI."""
+"""GPU parity of the strip matcher (forced with KERNEL_STRIP) against the oracle, and of the default matcher choice
+against both forced kernels.  Bit-exact bar; calls go through the C ABI.  The family has two members: sad_strip_kernel
+(operands pre-packed in LDS; D > 64) and sad_strip_otf_kernel (operands packed on the fly; D <= 64); tests that take
+the `form` fixture run once with the default choice and once with SADBM_OTF=0, i.e. sad_strip_kernel at every D."""
 import numpy as np
 import pytest
 import opencv_amd as oa
 import oracle
-from helpers import noise_pair
+from helpers import noise_pair, strip_kernel_name
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["default", "staged"])
+def form(request, monkeypatch):
+    if request.param == "staged":
+        monkeypatch.setenv("SADBM_OTF", "0")
+    else:
+        monkeypatch.delenv("SADBM_OTF", raising=False)
+    oa.reload_env()
+    return request.param == "staged"
 
 
 def dev(a):
@@ -16,14 +28,14 @@ def dev(a):
 
 @pytest.mark.parametrize("win,D", [(15, 128), (7, 30), (9, 64), (7, 128), (21, 256), (4, 64), (5, 17), (6, 70), (8, 100), (12, 64), (13, 200),
                                    (14, 64), (16, 129), (17, 64), (20, 64), (25, 256), (10, 1), (11, 16)])
-def test_strip_small(win, D):
+def test_strip_small(win, D, form):
     for (H, W) in ((61, 203), (70, 333), (40, 600)):
         for binary in (False, True):
             L, R = noise_pair(win * 977 + D + W, H, W, shift=5, binary=binary)
             exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
             ctx = oa.Context(0)
             got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
-            assert ctx.last_kernel() == "sad_strip_kernel<%d>" % win
+            assert ctx.last_kernel() == strip_kernel_name(win, D, form)
             bad = np.argwhere(got != exp)
             assert bad.size == 0, (win, D, H, W, binary, len(bad), bad[:8], got[tuple(bad[0])], exp[tuple(bad[0])])
 
@@ -71,16 +83,17 @@ def test_strip_full_size_4k_band():
     assert np.array_equal(got[r0: r0 + n], exp)
 
 
-def test_strip_32_disparity_blocks_batches_bands_and_borders():
-    """The 128-thread / 32-disparity form of the strip matcher (D <= 32: the reference's own DSR = 30): batches with frame
-    groups, a row band, BGR, D not a multiple of 16, binary dots (ties), the reference's own pair."""
+def test_strip_short_searches_batches_bands_and_borders(form):
+    """Searches of at most 64 disparities (the reference's own DSR = 30; 64-, 128- and 256-thread blocks of the on-the-fly form):
+    batches with frame groups, a row band, BGR, D not a multiple of 16, binary dots (ties), the reference's own pair."""
     import torch
     from helpers import tsukuba_bgr
-    for (H, W, n, win, D) in ((61, 517, 5, 7, 30), (40, 1242, 3, 9, 32), (90, 384, 8, 7, 17), (33, 260, 4, 15, 31), (50, 300, 2, 21, 24)):
-        Ls, Rs = zip(*[oracle.rds(70 + i, W, H, 2 + i, min(D - 1, 12 + i), i & 1) for i in range(n)])
+    for (H, W, n, win, D) in ((61, 517, 5, 7, 30), (40, 1242, 3, 9, 32), (90, 384, 8, 7, 17), (33, 260, 4, 15, 31), (50, 300, 2, 21, 24), (60, 384, 6, 7, 12),
+                             (45, 700, 3, 17, 16), (64, 517, 4, 9, 64), (40, 640, 3, 15, 48), (30, 530, 5, 25, 5)):
+        Ls, Rs = zip(*[oracle.rds(70 + i, W, H, 2 + i % 3, min(D - 1, 12 + i), i & 1) for i in range(n)])
         ctx = oa.Context(0)
         out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
-        assert ctx.last_kernel() == "sad_strip_kernel<%d>" % win
+        assert ctx.last_kernel() == strip_kernel_name(win, D, form)
         for i in range(n):
             assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), (H, W, win, D, i)
         r0, nb = H // 3, H // 3
@@ -95,7 +108,7 @@ def test_strip_32_disparity_blocks_batches_bands_and_borders():
 
 
 @pytest.mark.parametrize("shape", [(9, 300), (300, 9), (40, 17), (8, 8), (16, 50), (50, 16), (1, 1), (33, 129), (20, 255), (20, 257), (20, 513)])
-def test_strip_small_and_degenerate_shapes(shape):
+def test_strip_small_and_degenerate_shapes(shape, form):
     """Shapes around the strip (16), block (256) and window sizes, W < D, W <= win, H <= win -- forced strip matcher."""
     H, W = shape
     L, R = noise_pair(H * 31 + W, H, W)
@@ -121,26 +134,27 @@ def test_strip_constant_identical_and_binary_ties():
 
 
 @pytest.mark.parametrize("win", list(range(4, 26)))
-def test_strip_every_window_instantiation(win):
-    """Every window the strip matcher is instantiated for (its geometry is constexpr per WIN), at 64 / 128 / 256 disparity blocks."""
+def test_strip_every_window_instantiation(win, form):
+    """Every window the strip matchers are instantiated for (their geometry is constexpr per WIN), at every block size:
+    16 / 32 / 64 disparities (on-the-fly form, or 64-disparity blocks of the staged form) and 128 / 256."""
     L, R = noise_pair(900 + win, 57, 283, shift=7)
-    for D in (9, 30, 32, 50, 97, 256):                             # 32- (two classes per wave), 64-, 128- and 256-disparity blocks
+    for D in ((9, 16, 30, 32, 50, 64) if not form else (9, 30, 50)) + (97, 256):
         ctx = oa.Context(0)
         got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
-        assert ctx.last_kernel() == "sad_strip_kernel<%d>" % win
+        assert ctx.last_kernel() == strip_kernel_name(win, D, form)
         assert np.array_equal(got, oracle.box(L, R, win, D, oracle.RAW_LOC)), (win, D)
 
 
 @pytest.mark.parametrize("shape,pairs", [((40, 203), 5), ((33, 640), 3), ((25, 100), 7), ((20, 16), 9), ((30, 250), 2), ((22, 1242), 4),
                                          ((12, 37), 33)])
-def test_strip_frame_groups(shape, pairs, monkeypatch):
+def test_strip_frame_groups(shape, pairs, monkeypatch, form):
     """Batches whose frame width is not a multiple of 256: the strip matcher lays several frames side by side in one
     plane (run_pipeline / strip_frame_groups) -- every frame still equals the oracle, for widths that are not multiples
     of 16, short last groups, BGR input, an unaligned output, a border-heavy D and one group per frame forced."""
     import torch
     H, W = shape
     Ls, Rs = zip(*[noise_pair(31 * W + i, H, W, shift=3 + i % 5) for i in range(pairs)])
-    for win, D in ((7, 128), (9, 64), (15, 130), (21, 256)):
+    for win, D in ((7, 128), (9, 64), (15, 130), (21, 256), (7, 30), (13, 16)) if not form else ((9, 64), (7, 30)):
         exp = [oracle.box(Ls[i], Rs[i], win, D) for i in range(pairs)]
         for fg in (None, "1", "3"):
             if fg is None:
@@ -150,7 +164,7 @@ def test_strip_frame_groups(shape, pairs, monkeypatch):
             oa.reload_env()
             ctx = oa.Context(0)
             out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
-            assert ctx.last_kernel() == ("sad_strip_kernel<%d>" % win if H > win and W > win else "none")
+            assert ctx.last_kernel() == (strip_kernel_name(win, D, form) if H > win and W > win else "none")
             for i in range(pairs):
                 bad = np.argwhere(out[i] != exp[i])
                 assert bad.size == 0, (shape, pairs, win, D, fg, i, len(bad), bad[:6])

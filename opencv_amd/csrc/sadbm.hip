@@ -199,6 +199,7 @@ struct sadbm_ctx {
     uint8_t *planes = nullptr;             // scratch: L planes then R planes
     size_t planes_cap = 0;
     bool planes_fixed = false;             // planes is not ours to grow or free (sadbm_compute_device_static)
+    bool host_inputs = false;              // set by the host API round its zero-copy call: the inputs are pinned host memory
     uint8_t *stage_in = nullptr;           // host API staging (device copies of the caller's host images)
     size_t stage_in_cap = 0;
     uint8_t *stage_out = nullptr;
@@ -407,6 +408,8 @@ struct EnvKnobs {
     int quad_half = -1;          // SADBM_QUAD_HALF  half-width (128-thread) blocks of the quad matcher: -1 choose, 0 never, 1 always
     int otf = -1;                // SADBM_OTF        on-the-fly form of the strip matcher (strip_otf_kernels.hip): -1 choose, 0 never, 1 whenever D <= 64
     int otf_ng = 0;              // SADBM_OTF_NG     its disparity groups per block: 0 choose (fewest that cover D), 1, 2 or 4
+    int trace = 0;               // SADBM_TRACE      1: one line per matcher launch on stderr (kernel, grid shape)
+    int direct = -1;             // SADBM_DIRECT     on-the-fly form reading the caller's 1-channel images itself (no prep pass): -1 choose, 0 never, 1 whenever possible
     long zc_bytes = 1 << 20;     // SADBM_ZEROCOPY_BYTES  host API: inputs up to this size are read by the GPU from pinned host memory
 };
 EnvKnobs read_env()
@@ -420,6 +423,8 @@ EnvKnobs read_env()
     k.kc = geti("SADBM_KC", 0); if (k.kc != 8 && k.kc != 16) k.kc = 0;
     k.quad_half = geti("SADBM_QUAD_HALF", -1); if (k.quad_half < 0 || k.quad_half > 1) k.quad_half = -1;
     k.otf = geti("SADBM_OTF", -1); if (k.otf < 0 || k.otf > 1) k.otf = -1;
+    k.trace = geti("SADBM_TRACE", 0);
+    k.direct = geti("SADBM_DIRECT", -1); if (k.direct < 0 || k.direct > 1) k.direct = -1;
     k.otf_ng = geti("SADBM_OTF_NG", 0); if (k.otf_ng != 1 && k.otf_ng != 2 && k.otf_ng != 4) k.otf_ng = 0;
     if (const char *e = getenv("SADBM_ZEROCOPY_BYTES")) k.zc_bytes = atol(e);
     return k;
@@ -456,13 +461,42 @@ int strip_band_rows(int bx, int n_pairs, int nvalid, int win, int NG, int n_cus)
     return best_ty;
 }
 
+// Rows per block of the on-the-fly kernels (64-256 threads, 4-16 blocks per CU).  Fitted to SADBM_STRIP_TY sweeps on MI355X
+// (tools/ty_otf.py, profiles/r02e_otf_rows_per_block.txt): with that many small blocks per CU the rounds of block slots blur
+// into a stream -- a job of R rounds of block slots takes about R + 0.4 block durations, whether R is 0.7 or 16 (a little
+// less when the blocks just fill a round; never less than ~0.6: with few blocks a step costs its latency) -- and a block
+// lasts ty output steps, win-1 warm-up steps at about half price (no SUB pass, no key phase) and one step's worth of set-up.
+int otf_band_rows(int bx, int n_groups, int nvalid, int win, int NG, int n_cus)
+{
+    if (env().strip_ty) return env().strip_ty;
+    const double slots = (double)n_cus * (16 / NG);
+    const long cols = (long)bx * n_groups;
+    double best = 1e30; int best_ty = 1;
+    for (int ty = 1; ty <= 256 && ty <= nvalid; ++ty) {
+        const long nby = (nvalid + ty - 1) / ty;
+        if (ty > 1 && nby == (nvalid + ty - 2) / (ty - 1)) continue;     // same band count as ty - 1: the shorter bands win
+        const double R = (double)(cols * nby) / slots;
+        double f = R + 0.4;
+        if (R < 4.0 && R - (double)(long)R >= 0.96) f -= 0.2;            // the blocks just fill their last round
+        if (f < 0.6) f = 0.6;                                              // too few blocks: a step costs its latency
+        const double cost = f * (ty + 0.5 * (win - 1) + 1.0);
+        if (cost < best) { best = cost; best_ty = ty; }
+    }
+    // the last band is shorter: even the rows out over the bands
+    const long nby = (nvalid + best_ty - 1) / best_ty;
+    return (int)((nvalid + nby - 1) / nby);
+}
+
 // Frames per plane group for the strip matcher: fewest 256-column blocks over the batch, groups at most 16K columns
 // wide; one frame per plane unless grouping saves at least 1.5 % of the blocks.  Wp = frame pitch in columns (x16).
-void strip_frame_groups(int cols, int n_pairs, int *FG, int *Wp)
+// gap: columns that must lie between the end of a frame and the next one (15 for the direct-reading kernels, whose
+// 16-byte units must not hold bytes of two frames; Wp then applies to single frames too); *nblocks = 256-column blocks.
+void strip_frame_groups(int cols, int n_pairs, int gap, int *FG, int *Wp, long *nblocks)
 {
-    *FG = 1; *Wp = cols;
+    const int wp = (cols + gap + 15) & ~15;
+    *FG = 1; *Wp = gap ? wp : cols;
+    *nblocks = (long)n_pairs * ((cols + 255) / 256);
     const int efg = env().strip_fg;
-    const int wp = (cols + 15) & ~15;
     if (n_pairs < 2 || efg == 1) return;
     auto width = [&](int nf) { return ((long)(nf - 1) * wp + cols + 255) / 256; };   // column blocks of a plane holding nf frames
     auto blocks = [&](int fg) { return (long)(n_pairs / fg) * width(fg) + (n_pairs % fg ? width(n_pairs % fg) : 0); };
@@ -473,7 +507,7 @@ void strip_frame_groups(int cols, int n_pairs, int *FG, int *Wp)
         const long b = blocks(fg);
         if (b < best) { best = b; best_fg = fg; }
     }
-    if (best_fg > 1 && (double)best <= 0.985 * (double)blocks(1)) { *FG = best_fg; *Wp = wp; }
+    if (best_fg > 1 && (double)best <= 0.985 * (double)blocks(1)) { *FG = best_fg; *Wp = wp; *nblocks = best; }
 }
 
 // Default matcher choice, from tools/sweep.py on MI355X (profiles/r01h_sweep_*.txt, profiles/r01k_sweep_*.txt): the strip
@@ -547,7 +581,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     int otf_lds = 0;
     int otf_ng = D <= 16 ? 1 : D <= 32 ? 2 : 4;
     if (env().otf_ng > otf_ng) otf_ng = env().otf_ng;
-    strip_kernel_t sk_otf = (D <= 64 && win <= MAXWIN && cols < 65000 && env().otf != 0) ? pick_strip_otf_kernel(win, otf_ng, &otf_lds) : nullptr;
+    strip_kernel_t sk_otf = (D <= 64 && win <= MAXWIN && cols < 65000 && env().otf != 0) ? pick_strip_otf_kernel(win, otf_ng, false, &otf_lds) : nullptr;
     const bool use_otf = sk_otf != nullptr && (env().otf == 1 || otf_is_default(win, D, cols, nvalid, n_pairs));
     if (use_otf) { sk = sk_otf; strip_ng = otf_ng; }
     if (sk && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL | SADBM_KERNEL_QUAD))) {
@@ -560,8 +594,23 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     // empty (1920: 6 %, 640: 19 %): it gets FG frames side by side in one plane, Wp columns apart, and treats the group
     // as one wide frame whose strips know their frame (sad_strip.inc).
     int FG = 1, Wp = cols;
-    if (use_strip) strip_frame_groups(cols, n_pairs, &FG, &Wp);
-    if (use_strip && ((size_t)(PADL + (size_t)(FG - 1) * Wp + cols + PADR + 127) & ~(size_t)127) * (size_t)need_rows > 0x7ff00000u) {
+    long blocksg = 0;
+    if (use_strip) strip_frame_groups(cols, n_pairs, 0, &FG, &Wp, &blocksg);
+    // The on-the-fly form can read single-channel inputs itself: no prep pass (7-8 % of a step at D <= 32, 4 % at 64, and
+    // one launch less per call).  Every frame is then a group of its own: groups of direct-read frames need 15 columns
+    // between frames and measured no faster than single frames (tools/fg_otf.py, profiles/r02e_otf_direct_frame_groups.txt),
+    // so batches whose frame groups save more blocks than the prep pass costs keep the prep pass.  Not for inputs the GPU
+    // reads over PCIe (the host API's zero-copy staging): the matcher reads every byte ~5 times.
+    bool direct = use_strip && use_otf && channels == 1 && !ctx->host_inputs && env().direct != 0 && cols + 32 < 65000 &&
+                  (int64_t)need_rows * (pitchL > pitchR ? pitchL : pitchR) < 0x7ff00000LL;
+    if (direct) {
+        int fgd = 1, wpd = cols; long blocksd = 0;
+        strip_frame_groups(cols, env().direct == 1 ? n_pairs : 1, 15, &fgd, &wpd, &blocksd);   // SADBM_DIRECT=1: direct-read groups too (tests)
+        if (env().direct < 0) blocksd = (long)n_pairs * ((cols + 255) / 256);
+        if (env().direct < 0 && (double)blocksd > (double)blocksg * (otf_ng <= 2 ? 1.06 : 1.03)) direct = false;
+        else { FG = fgd; Wp = wpd; sk = pick_strip_otf_kernel(win, otf_ng, true, &otf_lds); }
+    }
+    if (use_strip && !direct && ((size_t)(PADL + (size_t)(FG - 1) * Wp + cols + PADR + 127) & ~(size_t)127) * (size_t)need_rows > 0x7ff00000u) {
         FG = 1; Wp = cols;                                    // the strip matcher addresses the R plane with 32-bit offsets
         if ((size_t)((PADL + cols + PADR + 127) & ~127) * (size_t)need_rows > 0x7ff00000u) use_strip = false;
     }
@@ -574,8 +623,8 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     // scratch layout: [group][L plane | R plane], + slack: the strip matcher stages whole 256-column blocks
     // and may read a few hundred bytes past the last row (values only reach columns >= cols-win, which are 0)
     const size_t planes_need = 2 * plane_bytes * (size_t)n_groups + 4096;
-    if (ctx->planes_fixed && planes_need > ctx->planes_cap) return SADBM_E_LIMIT;     // static scratch: never grown
-    int rc = ctx->planes_fixed ? SADBM_OK : grow(&ctx->planes, &ctx->planes_cap, planes_need);
+    if (ctx->planes_fixed && planes_need > ctx->planes_cap) return SADBM_E_LIMIT;     // static scratch: never grown (one documented limit, direct or not)
+    int rc = (ctx->planes_fixed || direct) ? SADBM_OK : grow(&ctx->planes, &ctx->planes_cap, planes_need);
     if (rc) return rc;
     uint8_t *pL = ctx->planes, *pR = ctx->planes + plane_bytes;
 
@@ -592,9 +641,11 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     }
     if (env().prep_bx) pbx = env().prep_bx;
     dim3 pg((cpr + pbx - 1) / pbx, (need_rows + PREP_ROWS - 1) / PREP_ROWS, 2 * n_groups);   // n_groups <= 32767 (callers chunk)
-    hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(pbx), 0, st, dL, pitchL, dR, pitchR, pair_stride_in, channels, need_rows, cols, pL, pitch,
-                       (int64_t)plane_bytes, FG, Wp, Wp_magic, n_pairs);
-    HIPCHK(hipGetLastError());
+    if (!direct) {
+        hipLaunchKernelGGL(prep_plane_kernel, pg, dim3(pbx), 0, st, dL, pitchL, dR, pitchR, pair_stride_in, channels, need_rows, cols, pL, pitch,
+                           (int64_t)plane_bytes, FG, Wp, Wp_magic, n_pairs);
+        HIPCHK(hipGetLastError());
+    }
 
     Params p;
     p.L = pL + PADL; p.R = pR + PADL; p.plane_stride = (int64_t)(2 * plane_bytes); p.pitch = pitch;
@@ -610,11 +661,14 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         q.Lrow0 = pL; q.pair_stride = (int64_t)(2 * plane_bytes); q.lr_delta = (uint32_t)plane_bytes;
         q.pitch = pitch; q.W = cols; q.nvalid = nvalid; q.win = win; q.D = D;
         q.out = dOut; q.out_pitch = out_pitch; q.out_stride = pair_stride_out; q.flags = flags; q.dword_store = p.dword_store;
+        q.dL = dL; q.dR = dR; q.in_stride = pair_stride_in; q.pitchL = (int)pitchL; q.pitchR = (int)pitchR;
+        q.extL = direct ? (int)((int64_t)(need_rows - 1) * pitchL + cols) : 0;
+        q.extR = direct ? (int)((int64_t)(need_rows - 1) * pitchR + cols) : 0;
         const int bx = (vcols + strip::XBW - 1) / strip::XBW;
         // rows per block: a block is 64*NG threads and two blocks fit a CU only up to NG = 8, so the grid is a few
         // hundred large blocks and its quantisation matters.  Minimise rounds x steps-per-block over band heights
         // that fill whole rounds of block slots (a round whose CUs hold a single block runs ~0.65 as long).
-        int TY = strip_band_rows(bx, n_groups, nvalid, win, q.NG, ctx->cus);
+        int TY = use_otf ? otf_band_rows(bx, n_groups, nvalid, win, q.NG, ctx->cus) : strip_band_rows(bx, n_groups, nvalid, win, q.NG, ctx->cus);
         q.TY = TY;
         const int NSL = strip::NS + q.NG;
         int PR = 0, ROWW = 0;
@@ -627,9 +681,12 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         const long nblocks = (long)q.nbx * q.nby * q.ngroups;
         if (nblocks > 0x7ffffff0L) return SADBM_E_SIZE;
         dim3 g((unsigned)((nblocks + 7) & ~7L));               // 1-D, XCD-aware order decoded in the kernel
+        if (env().trace)
+            fprintf(stderr, "sadbm: strip%s win %d D %d NG %d direct %d  %dx%d x%d  FG %d Wp %d  bx %d nby %d groups %d TY %d  lds %zu\n", use_otf ? "_otf" : "",
+                    win, D, q.NG, (int)direct, cols, nvalid, n_pairs, FG, Wp, q.nbx, q.nby, q.ngroups, TY, lds);
         hipLaunchKernelGGL(sk, g, dim3(64 * q.NG), lds, st, q);
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), use_otf ? "sad_strip_otf_kernel<%d>" : "sad_strip_kernel<%d>", win);
-        if (use_otf) snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_strip_otf_kernel<%d,%d>", win, otf_ng);
+        if (use_otf) snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_strip_otf_kernel<%d,%d>%s", win, otf_ng, direct ? "+direct" : "");
         HIPCHK(hipGetLastError());
         if (prof) { HIPCHK(hipEventRecord(ev[2], st)); ctx->ev_n++; }
         return SADBM_OK;
@@ -1050,7 +1107,9 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
     copy_rows(hL, (int64_t)pin, left->data, left->step, (size_t)cols, rows, ch);
     copy_rows(hR, (int64_t)pin, right->data, right->step, (size_t)cols, rows, ch);
     if (!zero_copy) HIPCHK(hipMemcpyAsync(dL, hL, in_bytes, hipMemcpyHostToDevice, st));
+    ctx->host_inputs = zero_copy;
     rc = sadbm_compute_device(ctx, dL, (int64_t)pin, dR, (int64_t)pin, rows, cols, 1, win, max_disp, flags, dO, (int64_t)pout, st);
+    ctx->host_inputs = false;
     if (rc) return rc;
     if (!zero_copy) HIPCHK(hipMemcpyAsync(ctx->pin_out, dO, out_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

@@ -45,6 +45,11 @@ struct SParams {
     int nbx, nby, ngroups;    // column blocks, row bands, frame groups: the launch is 1-D over their product (padded to 8)
     int FG, Wp, npairs;       // a group = FG frames side by side in one plane, Wp columns apart (Wp % 16 == 0); total frames
     int rows_out;             // output rows [nvalid, rows_out) are zero-filled by the blocks of the last band
+    // direct variant of sad_strip_otf_kernel only: the caller's images (single channel), frames in_stride bytes apart; every
+    // byte [0, ext) from a frame's first byte is readable (ext = (rows read - 1) * pitch + cols < 2^31)
+    const uint8_t *dL, *dR;
+    int64_t in_stride;
+    int pitchL, pitchR, extL, extR;
     uint8_t *out;
     int64_t out_pitch, out_stride;
     uint32_t flags;
@@ -61,7 +66,8 @@ quad_kernel_t pick_quad_lds_kernel(int win, int kc);     // sad_quad_lds_kernel<
 // strip_kernels.hip: nslm = NS + (4, 8 or 16 disparity groups); nullptr where the window has no strip instantiation
 strip_kernel_t pick_strip_kernel(int win, int nslm);
 // strip_otf_kernels.hip: the on-the-fly form of the strip matcher, ng = 1, 2 or 4 disparity groups per block (64 ng threads); its dynamic LDS size
-strip_kernel_t pick_strip_otf_kernel(int win, int ng, int *lds_bytes);
+// direct: the variant that reads the caller's single-channel images itself (SParams::dL ...) instead of padded planes
+strip_kernel_t pick_strip_otf_kernel(int win, int ng, bool direct, int *lds_bytes);
 // host copies of the strip kernel's compile-time geometry: staging passes per row image, dwords per row image
 void strip_geometry(int win, int nsl, int *pr, int *roww);
 

@@ -108,7 +108,12 @@ __device__ __forceinline__ void strip_pass_otf(const uint32_t *pL, const uint32_
     }
 }
 
-template <int WIN, int NG_>
+// DIRECT: the staging units are read from the caller's single-channel images themselves (no prep_plane_kernel pass, no
+// scratch planes; one frame per "group").  A unit that would leave the frame's bytes [0, ext) -- left of column 0 in the
+// first row, past the last row's end -- is assembled byte by byte with zeros outside; everywhere else bytes beyond a
+// row's ends are the neighbouring rows' (or the pitch padding's) instead of zeros, and like the zeros of the padded
+// planes they only ever reach slots that never compete (k > column) and columns >= cols - win, which are written as 0.
+template <int WIN, int NG_, bool DIRECT>
 __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
 {
     using G = SG<WIN>;
@@ -135,7 +140,7 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
     if (XB >= (nf - 1) * p.Wp + p.W) return;                  // block-uniform
     const int yb = byi * p.TY;
     const int ny = min(p.TY, p.nvalid - yb);
-    const uint8_t *Lbase = p.Lrow0 + (int64_t)pz * p.pair_stride;
+    const uint8_t *Lbase = p.Lrow0 + (int64_t)pz * p.pair_stride;   // padded planes (not DIRECT)
     const int ocols = p.W - p.win;
 
     for (int i = tid; i < 2 * 4 * 64; i += nthr) cells[i] = KEY_MAX;
@@ -146,16 +151,28 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
 
     // ---- staging role of this lane: units tid (+ nthr) of every row image (16 bytes of LP, or of RP[c]) ----
     constexpr int UPL = O::UPL;
-    uint32_t uoff[UPL]; int udst[UPL];
+    // DIRECT: a unit belongs to the frame of its LAST byte: frames are Wp >= cols + 15 columns apart, so whatever precedes
+    // that frame's column 0 inside the unit lies in the gap behind the previous frame (only zeroed columns read it); the
+    // unit's bytes left of column 0 come from the row above, and reach only slots that never compete (k > column).
+    uint32_t uoff[UPL]; int udst[UPL]; bool uright[UPL]; const uint8_t *ubase[UPL];
 #pragma unroll
     for (int j = 0; j < UPL; ++j) {
         const int u = tid + j * nthr;
-        uoff[j] = 0; udst[j] = -1;
+        uoff[j] = 0; udst[j] = -1; uright[j] = false; ubase[j] = nullptr;
+        int P = 0;                                            // first column of the unit in the group's plane
         if (u < NS + 2) {
-            uoff[j] = (uint32_t)(PADL + XB + 16 * u); udst[j] = 4 * u;
+            P = XB + 16 * u; udst[j] = 4 * u;
+            uoff[j] = (uint32_t)(PADL + P);
         } else if (u < O::NUNITS) {
             const int v = u - (NS + 2), c = v / O::RPS, slot = v - c * O::RPS;
-            uoff[j] = p.lr_delta + (uint32_t)(PADL + XB - c + 16 * (slot - NG)); udst[j] = O::OFF_RP + c * O::SRP + 4 * slot;
+            P = XB - c + 16 * (slot - NG);
+            uoff[j] = p.lr_delta + (uint32_t)(PADL + P);
+            udst[j] = O::OFF_RP + c * O::SRP + 4 * slot; uright[j] = true;
+        }
+        if constexpr (DIRECT) {
+            const int f = P + 15 >= 0 ? (P + 15) / p.Wp : 0;
+            uoff[j] = (uint32_t)(P - f * p.Wp);              // column within the frame, -35 ... Wp - 16
+            if (f < nf) ubase[j] = (uright[j] ? p.dR : p.dL) + (int64_t)(pz * p.FG + f) * p.in_stride;   // else: no such frame, zeros
         }
     }
     // row `row` of the plane -> row slot `slot` of buffer `buf`
@@ -165,7 +182,23 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
 #pragma unroll
         for (int j = 0; j < UPL; ++j) {
             q.w[j] = u32x4u{0, 0, 0, 0};
-            if (udst[j] >= 0) q.w[j] = *(const u32x4u *)(Lbase + (int64_t)row * p.pitch + uoff[j]);
+            if constexpr (!DIRECT) {
+                if (udst[j] >= 0) q.w[j] = *(const u32x4u *)(Lbase + (int64_t)row * p.pitch + uoff[j]);
+            } else if (udst[j] >= 0 && ubase[j] != nullptr) {
+                const int o = (uright[j] ? row * p.pitchR : row * p.pitchL) + (int)uoff[j];   // byte offset within the frame
+                const uint8_t *b = ubase[j];
+                const int ext = uright[j] ? p.extR : p.extL;
+                if (o >= 0 && o + 16 <= ext) {
+                    q.w[j] = *(const u32x4u *)(b + o);
+                } else {                                      // first row left of column 0, or the tail of the last rows
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (int i = 0; i < 16; ++i) {
+                        const int oi = o + i;
+                        if (oi >= 0 && oi < ext) w[i >> 2] |= (uint32_t)b[oi] << (8 * (i & 3));
+                    }
+                    q.w[j] = u32x4u{w[0], w[1], w[2], w[3]};
+                }
+            }
         }
         return q;
     };
@@ -261,16 +294,16 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
 
 }  // namespace strip
 
-strip_kernel_t otf_part_1(int win, int *lds_bytes);
-strip_kernel_t otf_part_2(int win, int *lds_bytes);
-strip_kernel_t otf_part_4(int win, int *lds_bytes);
+strip_kernel_t otf_part_1(int win, bool direct, int *lds_bytes);
+strip_kernel_t otf_part_2(int win, bool direct, int *lds_bytes);
+strip_kernel_t otf_part_4(int win, bool direct, int *lds_bytes);
 
 namespace {
 constexpr int PNG = SADBM_OTF_PART_NG;
-template <int WIN>
+template <int WIN, bool DIRECT>
 static strip_kernel_t otf_entry()
 {
-    if constexpr (WIN >= 4 && strip::SG<WIN>::ok && strip::OG<WIN, PNG>::ok) return strip::sad_strip_otf_kernel<WIN, PNG>;
+    if constexpr (WIN >= 4 && strip::SG<WIN>::ok && strip::OG<WIN, PNG>::ok) return strip::sad_strip_otf_kernel<WIN, PNG, DIRECT>;
     else return nullptr;
 }
 template <int WIN>
@@ -280,10 +313,11 @@ static int otf_lds_one()
     else return 0;
 }
 template <int... I>
-strip_kernel_t otf_table(int win, Seq<I...>)
+strip_kernel_t otf_table(int win, bool direct, Seq<I...>)
 {
-    static const strip_kernel_t t[] = { otf_entry<I + 1>()... };
-    return t[win - 1];
+    static const strip_kernel_t t[] = { otf_entry<I + 1, false>()... };
+    static const strip_kernel_t td[] = { otf_entry<I + 1, true>()... };
+    return direct ? td[win - 1] : t[win - 1];
 }
 template <int... I>
 int otf_lds_table(int win, Seq<I...>)
@@ -295,17 +329,17 @@ int otf_lds_table(int win, Seq<I...>)
 
 #define SADBM_CAT2(a, b) a##b
 #define SADBM_CAT(a, b) SADBM_CAT2(a, b)
-strip_kernel_t SADBM_CAT(otf_part_, SADBM_OTF_PART_NG)(int win, int *lds_bytes)
+strip_kernel_t SADBM_CAT(otf_part_, SADBM_OTF_PART_NG)(int win, bool direct, int *lds_bytes)
 {
     if (lds_bytes) *lds_bytes = otf_lds_table(win, MakeSeq<MAXWIN>::type());
-    return otf_table(win, MakeSeq<MAXWIN>::type());
+    return otf_table(win, direct, MakeSeq<MAXWIN>::type());
 }
 
 #if SADBM_OTF_PART_NG == 2
-strip_kernel_t pick_strip_otf_kernel(int win, int ng, int *lds_bytes)
+strip_kernel_t pick_strip_otf_kernel(int win, int ng, bool direct, int *lds_bytes)
 {
     if (win < 1 || win > MAXWIN) return nullptr;
-    return ng == 1 ? otf_part_1(win, lds_bytes) : ng == 2 ? otf_part_2(win, lds_bytes) : ng == 4 ? otf_part_4(win, lds_bytes) : nullptr;
+    return ng == 1 ? otf_part_1(win, direct, lds_bytes) : ng == 2 ? otf_part_2(win, direct, lds_bytes) : ng == 4 ? otf_part_4(win, direct, lds_bytes) : nullptr;
 }
 #endif
 

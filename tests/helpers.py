@@ -56,3 +56,8 @@ def strip_kernel_name(win, D, staged=False):
     if not staged and D <= 64 and (win >= 5 or D <= 16):
         return "sad_strip_otf_kernel<%d,%d>" % (win, 1 if D <= 16 else 2 if D <= 32 else 4)
     return "sad_strip_kernel<%d>" % win
+
+
+def kname(ctx):
+    """Last kernel of a context without the "+direct" suffix (the on-the-fly form reading the caller's images itself)."""
+    return ctx.last_kernel().split("+")[0]

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import opencv_amd as oa
 import oracle
-from helpers import noise_pair, strip_kernel_name
+from helpers import kname, noise_pair, strip_kernel_name
 
 pytestmark = pytest.mark.gpu
 
@@ -35,7 +35,7 @@ def test_strip_small(win, D, form):
             exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
             ctx = oa.Context(0)
             got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
-            assert ctx.last_kernel() == strip_kernel_name(win, D, form)
+            assert kname(ctx) == strip_kernel_name(win, D, form)
             bad = np.argwhere(got != exp)
             assert bad.size == 0, (win, D, H, W, binary, len(bad), bad[:8], got[tuple(bad[0])], exp[tuple(bad[0])])
 
@@ -93,7 +93,7 @@ def test_strip_short_searches_batches_bands_and_borders(form):
         Ls, Rs = zip(*[oracle.rds(70 + i, W, H, 2 + i % 3, min(D - 1, 12 + i), i & 1) for i in range(n)])
         ctx = oa.Context(0)
         out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
-        assert ctx.last_kernel() == strip_kernel_name(win, D, form)
+        assert kname(ctx) == strip_kernel_name(win, D, form)
         for i in range(n):
             assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), (H, W, win, D, i)
         r0, nb = H // 3, H // 3
@@ -141,7 +141,7 @@ def test_strip_every_window_instantiation(win, form):
     for D in ((9, 16, 30, 32, 50, 64) if not form else (9, 30, 50)) + (97, 256):
         ctx = oa.Context(0)
         got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
-        assert ctx.last_kernel() == strip_kernel_name(win, D, form)
+        assert kname(ctx) == strip_kernel_name(win, D, form)
         assert np.array_equal(got, oracle.box(L, R, win, D, oracle.RAW_LOC)), (win, D)
 
 
@@ -164,7 +164,7 @@ def test_strip_frame_groups(shape, pairs, monkeypatch, form):
             oa.reload_env()
             ctx = oa.Context(0)
             out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
-            assert ctx.last_kernel() == (strip_kernel_name(win, D, form) if H > win and W > win else "none")
+            assert kname(ctx) == (strip_kernel_name(win, D, form) if H > win and W > win else "none")
             for i in range(pairs):
                 bad = np.argwhere(out[i] != exp[i])
                 assert bad.size == 0, (shape, pairs, win, D, fg, i, len(bad), bad[:6])
@@ -180,3 +180,82 @@ def test_strip_frame_groups(shape, pairs, monkeypatch, form):
     for i in range(pairs):
         assert np.array_equal(got[i, :, 1:1 + W], oracle.box(Ls[i], Rs[i], win, D)), i
     assert (got[:, :, 0] == 7).all() and (got[:, :, 1 + W:] == 7).all()
+
+
+@pytest.mark.parametrize("win,D", [(7, 30), (9, 64), (15, 16), (21, 48), (4, 9), (25, 32)])
+def test_direct_reads_of_caller_images(win, D, monkeypatch):
+    """The on-the-fly form reads single-channel inputs itself (no prep pass, "+direct"): views at the very start and end of
+    their allocation (the byte-wise edge path), row-strided ROI views with different pitches for left and right, a larger
+    right image, pitch == cols (units run into the next rows), frames narrower than a 16-byte unit, batches, a row band --
+    equal to the oracle and to the prep-pass path (SADBM_DIRECT=0)."""
+    import torch
+    rng = np.random.default_rng(win * 100 + D)
+    for (H, W) in ((win + 3, 300), (40, 517), (win + 2, 9 + win), (win + 8, 256), (win + 1, 1000)):
+        L, R = noise_pair(H * 7 + W + D, H, W, shift=min(5, W - 1))
+        exp = oracle.box(L, R, win, D)
+        ctx = oa.Context(0)
+        # exact-size allocations: nothing readable before the first or after the last byte
+        got = oa.compute_device(dev(L), dev(R), win, D, 0, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel() == strip_kernel_name(win, D) + "+direct", ctx.last_kernel()
+        assert np.array_equal(got, exp), (H, W, "exact")
+        # ROI views: left inside a wider buffer at a column offset, right inside a taller and wider one (its own pitch)
+        bl = torch.from_numpy(rng.integers(0, 256, size=(H, W + 37), dtype=np.uint8)).cuda()
+        br = torch.from_numpy(rng.integers(0, 256, size=(H + 3, W + 80), dtype=np.uint8)).cuda()
+        bl[:, 5:5 + W] = dev(L); br[2:2 + H, 41:41 + W] = dev(R)
+        got = oa.compute_device(bl[:, 5:5 + W], br[2:2 + H, 41:41 + W], win, D, 0, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel().endswith("+direct")
+        assert np.array_equal(got, exp), (H, W, "roi")
+        # a larger right image (SAD.cpp:47 takes its ROI at the left image's coordinates)
+        Rb = rng.integers(0, 256, size=(H + 2, W + 9), dtype=np.uint8); Rb[:H, :W] = R
+        assert np.array_equal(oa.compute_device(dev(L), dev(Rb), win, D, 0, ctx=ctx).cpu().numpy(), exp), (H, W, "larger right")
+        monkeypatch.setenv("SADBM_DIRECT", "0")
+        oa.reload_env()
+        got0 = oa.compute_device(dev(L), dev(R), win, D, 0, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel() == strip_kernel_name(win, D)
+        assert np.array_equal(got0, exp)
+        monkeypatch.delenv("SADBM_DIRECT")
+        oa.reload_env()
+    # batches (frame width a multiple of 256: no frame groups to lose) and a row band of a taller frame
+    n, H, W = 5, 45, 512
+    Ls, Rs = zip(*[oracle.rds(30 + i, W, H, 1 + i % 3, min(D - 1, 9 + i), i & 1) for i in range(n)])
+    ctx = oa.Context(0)
+    out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, 0, ctx=ctx).cpu().numpy()
+    assert ctx.last_kernel().endswith("+direct")
+    for i in range(n):
+        assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), i
+    if H > win + 12:
+        r0, nb = 7, 12
+        i1 = min(r0 + nb + win - 1, H)
+        got = oa.compute_band_device(dev(Ls[0][r0:i1]), dev(Rs[0][r0:i1]), H, r0, nb, win, D, 0, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel().endswith("+direct")
+        assert np.array_equal(got, oracle.box(Ls[0], Rs[0], win, D)[r0:r0 + nb])
+
+
+@pytest.mark.parametrize("W", [384, 203, 16, 640])
+def test_direct_reads_with_frame_groups(W, monkeypatch):
+    """SADBM_DIRECT=1: direct reads also where frames share a group (not the default: measured no faster than single frames).
+    Frames lie 15+ columns apart in the group's column space, a 16-byte unit holds bytes of one frame only."""
+    monkeypatch.setenv("SADBM_DIRECT", "1")
+    oa.reload_env()
+    n, H = 9, 38
+    for win, D in ((7, 30), (9, 64), (13, 12)):
+        Ls, Rs = zip(*[noise_pair(W + 11 * i + win, H, W, shift=min(3 + i, W - 1), binary=bool(i & 1)) for i in range(n)])
+        ctx = oa.Context(0)
+        out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, 0, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel() == strip_kernel_name(win, D) + "+direct"
+        for i in range(n):
+            assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), (W, win, D, i)
+
+
+def test_direct_is_not_used_for_colour_or_host_mapped_inputs():
+    from helpers import tsukuba_bgr
+    L, R = tsukuba_bgr()
+    ctx = oa.Context(0)
+    exp = oracle.literal(np.ascontiguousarray(L[:, :, 0]), np.ascontiguousarray(R[:, :, 0]), 7, 30)
+    assert np.array_equal(oa.compute_device(dev(L), dev(R), 7, 30, ctx=ctx).cpu().numpy(), exp)
+    assert ctx.last_kernel() == "sad_strip_otf_kernel<7,2>"               # BGR: channel 0 goes through the prep pass
+    assert np.array_equal(oa.get_disparity_host(L, R, 7, 30, ctx=ctx), exp)
+    assert ctx.last_kernel() == "sad_strip_otf_kernel<7,2>"               # small host frames are read over PCIe: prep pass, once
+    big = np.ascontiguousarray(np.tile(L[:, :, 0], (3, 3))); bigr = np.ascontiguousarray(np.tile(R[:, :, 0], (3, 3)))
+    assert np.array_equal(oa.get_disparity_host(big, bigr, 7, 30, ctx=ctx), oracle.box(big, bigr, 7, 30))
+    assert ctx.last_kernel() == "sad_strip_otf_kernel<7,2>+direct"        # staged on the device first: read directly

@@ -601,7 +601,9 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     // between frames and measured no faster than single frames (tools/fg_otf.py, profiles/r02e_otf_direct_frame_groups.txt),
     // so batches whose frame groups save more blocks than the prep pass costs keep the prep pass.  Not for inputs the GPU
     // reads over PCIe (the host API's zero-copy staging): the matcher reads every byte ~5 times.
+    // (64-thread blocks with windows from 13 columns up: two staging units per lane, the direct variant spills 8-39 VGPRs)
     bool direct = use_strip && use_otf && channels == 1 && !ctx->host_inputs && env().direct != 0 && cols + 32 < 65000 &&
+                  !(otf_ng == 1 && win >= 13 && env().direct < 0) &&
                   (int64_t)need_rows * (pitchL > pitchR ? pitchL : pitchR) < 0x7ff00000LL;
     if (direct) {
         int fgd = 1, wpd = cols; long blocksd = 0;

@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
     const int xs = xv - fr * p.Wp;
     const bool active = (fr < nf) && (xs < ocols) && (kb < p.D) && (kb <= xs + 15);
     const bool diag = active && (kb + 12 > xs);
-    const bool mask_d = __any(active && (kb + 12 >= p.D));
+    const bool mask_d = G::POISON == 0 && __any(active && (kb + 12 >= p.D));   // see SG::POISON
     const bool any_diag = __any(diag);
     const EmitCtx ec = {kb, c, diag, {false, kb + 4 >= p.D, kb + 8 >= p.D, kb + 12 >= p.D}};
     const bool wave_active = __any(active);
@@ -230,8 +230,9 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
     uint32_t V[4][NV], E[4][4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+        const uint32_t v0 = (G::HI16 ? (uint32_t)(kb + 4 * t) : 0u) + (kb + 4 * t >= p.D ? (G::HI16 ? G::POISON << 16 : G::POISON) : 0u);
 #pragma unroll
-        for (int n = 0; n < NV; ++n) V[t][n] = G::HI16 ? (uint32_t)(kb + 4 * t) : 0u;
+        for (int n = 0; n < NV; ++n) V[t][n] = v0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { E[t][i][0] = 0; E[t][i][1] = 0; }
     }

@@ -189,6 +189,9 @@ def test_direct_reads_of_caller_images(win, D, monkeypatch):
     right image, pitch == cols (units run into the next rows), frames narrower than a 16-byte unit, batches, a row band --
     equal to the oracle and to the prep-pass path (SADBM_DIRECT=0)."""
     import torch
+    if D <= 16 and win >= 13:                                  # 64-thread blocks with wide windows keep the prep pass by default (spills)
+        monkeypatch.setenv("SADBM_DIRECT", "1")
+        oa.reload_env()
     rng = np.random.default_rng(win * 100 + D)
     for (H, W) in ((win + 3, 300), (40, 517), (win + 2, 9 + win), (win + 8, 256), (win + 1, 1000)):
         L, R = noise_pair(H * 7 + W + D, H, W, shift=min(5, W - 1))
@@ -213,7 +216,10 @@ def test_direct_reads_of_caller_images(win, D, monkeypatch):
         got0 = oa.compute_device(dev(L), dev(R), win, D, 0, ctx=ctx).cpu().numpy()
         assert ctx.last_kernel() == strip_kernel_name(win, D)
         assert np.array_equal(got0, exp)
-        monkeypatch.delenv("SADBM_DIRECT")
+        if D <= 16 and win >= 13:
+            monkeypatch.setenv("SADBM_DIRECT", "1")
+        else:
+            monkeypatch.delenv("SADBM_DIRECT")
         oa.reload_env()
     # batches (frame width a multiple of 256: no frame groups to lose) and a row band of a taller frame
     n, H, W = 5, 45, 512

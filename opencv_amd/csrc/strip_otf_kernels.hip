@@ -25,7 +25,7 @@ namespace sadbm_detail {
 
 namespace strip {
 
-template <int WIN, int NG_>
+template <int WIN, int NG_, bool DIRECT_ = false>
 struct OG {
     using G = SG<WIN>;
     static constexpr int NG = NG_;                               // disparity groups of 16 per block
@@ -47,23 +47,35 @@ struct OG {
     static constexpr bool run_ok(int a) { return (G::nl(a) == 0 || bl(a) + G::nl(a) <= 4) && (G::nh(a) == 0 || bh(a) + G::nh(a) <= 4); }
     static constexpr int wmax1(int a) { return G::ne(a) ? (wl(a) > wh(a) ? wl(a) : wh(a)) : 0; }
     static constexpr int WMAX = G::imax(G::imax(wmax1(0), wmax1(1)), G::imax(wmax1(2), wmax1(3)));
-    static constexpr int NLW = G::imax(G::NV, 3 + WMAX + 1);     // L words a strip reads (index of quad 3 + WMAX)
-    static constexpr int NRW = NLW + 4;                          // R words: index (word - t + 4), t = 0..3
+    // LVS: the E words of L are the same for every (class, group) of a strip -- 8 or 16 threads would pack the same 16 words
+    // per pass -- so blocks of two waves and more stage them once per row (the block's last wave: 64 units of 4 words, two
+    // loads and four permutes each, LV[a][4 NS]) and the passes read them with four ds_read_b128; R stays on the fly.
+    // Only at NG = 4, where a wave without plain units takes the LV units: a block is as fast as its slowest wave, and the
+    // packing wave of a two-wave block would win back 8 of its 32 permutes.  (NG = 1: one wave would pack for itself alone.)
+    // Only where the 14 more live registers do not spill: windows up to 13 of the plane-reading variant (2-4.5 % faster
+    // there; 15 and up, and the direct variant, measured 1-28 % slower: profiles/r02e_otf_lv_staging_ab.txt).
+#ifdef SADBM_OTF_NO_LVS
+    static constexpr bool LVS = false;                           // experiment builds
+#else
+    static constexpr bool LVS = NG >= 4 && WIN <= 13 && !DIRECT_;
+#endif
+    static constexpr int NLW = LVS ? G::NV : G::imax(G::NV, 3 + WMAX + 1);   // L words a strip reads (index of quad 3 + WMAX)
+    static constexpr int NRW = G::imax(G::NV, 3 + WMAX + 1) + 4; // R words: index (word - t + 4), t = 0..3
     static constexpr int NLWP = (NLW + 3) & ~3, NRWP = (NRW + 3) & ~3;
-    // LDS row image (dwords): LP[4 (NS+2)] | RP[4][4 RPS]
-    static constexpr int NLP = 4 * (NS + 2), SRP = 4 * RPS, OFF_RP = NLP, ROWW = OFF_RP + 4 * SRP;
-    static constexpr int NUNITS = (NS + 2) + 4 * RPS;            // 16-byte staging units per row image
-    static constexpr int UPL = (NUNITS + 64 * NG - 1) / (64 * NG);   // units per lane
+    // LDS row image (dwords): LP[4 (NS+2)] | LV[4][4 NS] (LVS) | RP[4][4 RPS]
+    static constexpr int NLP = 4 * (NS + 2), OFF_LV = NLP, SRP = 4 * RPS, OFF_RP = NLP + (LVS ? 16 * NS : 0), ROWW = OFF_RP + 4 * SRP;
+    static constexpr int NUNITS = (NS + 2) + 4 * RPS;            // plain 16-byte staging units per row image
+    static constexpr int UPL = (NUNITS + 64 * NG - 1) / (64 * NG);   // plain units per lane
     static constexpr bool ok = G::ok && run_ok(0) && run_ok(1) && run_ok(2) && run_ok(3) && NLWP <= 12 && NRWP <= 16 && UPL <= 2;
 };
 
 // One image row folded into the running sums of this thread (ADD: entering row, SUB: leaving row).
 //   pL: LP + 4*strip; pR: this thread's first R word in RP[c] (one slot below the slot of its (strip, group))
-template <int WIN, bool SUB>
+template <int WIN, int NG_, bool DIRECT, bool SUB>
 __device__ __forceinline__ void strip_pass_otf(const uint32_t *pL, const uint32_t *pR, uint32_t (&V)[4][SG<WIN>::NV], uint32_t (&E)[4][4][2])
 {
     using G = SG<WIN>;
-    using O = OG<WIN, 2>;                                        // word geometry only: the same for every NG
+    using O = OG<WIN, NG_, DIRECT>;
     constexpr int NV = G::NV;
     uint32_t lw[O::NLWP], rw[O::NRWP];
 #pragma unroll
@@ -84,11 +96,16 @@ __device__ __forceinline__ void strip_pass_otf(const uint32_t *pL, const uint32_
     for (int p = 0; p < 2; ++p) {
         constexpr int A0[2] = {0, 2}, A1[2] = {1, 3};
         const int a0 = A0[p], a1 = A1[p];
-        uint32_t l0[4], l1[4], r0[7], r1[7];
+        uint32_t l0[4] = {0, 0, 0, 0}, l1[4] = {0, 0, 0, 0}, r0[7], r1[7];
+        if constexpr (O::LVS) {
+            if (G::ne(a0) > 0) lds128(pL + O::OFF_LV + a0 * (4 * NS), l0);
+            if (G::ne(a1) > 0) lds128(pL + O::OFF_LV + a1 * (4 * NS), l1);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            l0[i] = G::ne(a0) ? __builtin_amdgcn_perm(lw[i + O::wh(a0)], lw[i + O::wl(a0)], O::sel(a0)) : 0u;
-            l1[i] = G::ne(a1) ? __builtin_amdgcn_perm(lw[i + O::wh(a1)], lw[i + O::wl(a1)], O::sel(a1)) : 0u;
+            for (int i = 0; i < 4; ++i) {
+                l0[i] = G::ne(a0) ? __builtin_amdgcn_perm(lw[i + O::wh(a0)], lw[i + O::wl(a0)], O::sel(a0)) : 0u;
+                l1[i] = G::ne(a1) ? __builtin_amdgcn_perm(lw[i + O::wh(a1)], lw[i + O::wl(a1)], O::sel(a1)) : 0u;
+            }
         }
 #pragma unroll
         for (int d = 0; d < 7; ++d) {                            // d = i - t + 3
@@ -117,7 +134,7 @@ template <int WIN, int NG_, bool DIRECT>
 __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
 {
     using G = SG<WIN>;
-    using O = OG<WIN, NG_>;
+    using O = OG<WIN, NG_, DIRECT>;
     constexpr int NV = G::NV;
     constexpr int ROWW = O::ROWW;
     constexpr int NG = O::NG;
@@ -175,30 +192,54 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
             if (f < nf) ubase[j] = (uright[j] ? p.dR : p.dL) + (int64_t)(pz * p.FG + f) * p.in_stride;   // else: no such frame, zeros
         }
     }
+    // 16 bytes of row `row`: at plane offset `off` (padded planes) or at column `off` of the frame at `b` (DIRECT)
+    auto fetch = [&](bool right, const uint8_t *b, uint32_t off, int row) -> u32x4u {
+        if constexpr (!DIRECT) {
+            return *(const u32x4u *)(Lbase + (int64_t)row * p.pitch + off);
+        } else {
+            if (b == nullptr) return u32x4u{0, 0, 0, 0};
+            const int o = (right ? row * p.pitchR : row * p.pitchL) + (int)off;   // byte offset within the frame
+            const int ext = right ? p.extR : p.extL;
+            if (o >= 0 && o + 16 <= ext) return *(const u32x4u *)(b + o);
+            uint32_t w[4] = {0, 0, 0, 0};                         // first row left of column 0, or the tail of the last rows
+            for (int i = 0; i < 16; ++i) {
+                const int oi = o + i;
+                if (oi >= 0 && oi < ext) w[i >> 2] |= (uint32_t)b[oi] << (8 * (i & 3));
+            }
+            return u32x4u{w[0], w[1], w[2], w[3]};
+        }
+    };
+    // LV unit of this lane (lanes of the last wave): E words of L for column offset lva, strip lvs
+    const bool lv_wave = O::LVS && wave == nwaves - 1;            // scalar
+    uint32_t lvo1 = 0, lvo2 = 0, lvsel = 0; int lvdst = 0; const uint8_t *lvbase = nullptr;
+    if constexpr (O::LVS) {
+        const int lva = lane >> 4, lvs = lane & 15;
+        const uint32_t sels[4] = {G::sel(0), G::sel(1), G::sel(2), G::sel(3)};
+        // a run that is empty reads where the other one does
+        const int lo0s[4] = {G::nl(0) ? G::lo0(0) : G::hi0(0), G::nl(1) ? G::lo0(1) : G::hi0(1), G::nl(2) ? G::lo0(2) : G::hi0(2), G::nl(3) ? G::lo0(3) : G::hi0(3)};
+        const int hi0s[4] = {G::nh(0) ? G::hi0(0) : lo0s[0], G::nh(1) ? G::hi0(1) : lo0s[1], G::nh(2) ? G::hi0(2) : lo0s[2], G::nh(3) ? G::hi0(3) : lo0s[3]};
+        int P = XB + 16 * lvs;
+        lvsel = sels[lva]; lvdst = O::OFF_LV + lva * (4 * NS) + 4 * lvs;
+        if constexpr (DIRECT) {
+            const int f = P / p.Wp;
+            P -= f * p.Wp;
+            if (f < nf) lvbase = p.dL + (int64_t)(pz * p.FG + f) * p.in_stride;
+        } else {
+            P += PADL;
+        }
+        lvo1 = (uint32_t)(P + lo0s[lva]); lvo2 = (uint32_t)(P + hi0s[lva]);
+    }
     // row `row` of the plane -> row slot `slot` of buffer `buf`
-    struct Units { u32x4u w[UPL]; };
+    struct Units { u32x4u w[UPL]; u32x4u v1, v2; };
     auto unit_load = [&](int row) -> Units {
         Units q;
 #pragma unroll
         for (int j = 0; j < UPL; ++j) {
             q.w[j] = u32x4u{0, 0, 0, 0};
-            if constexpr (!DIRECT) {
-                if (udst[j] >= 0) q.w[j] = *(const u32x4u *)(Lbase + (int64_t)row * p.pitch + uoff[j]);
-            } else if (udst[j] >= 0 && ubase[j] != nullptr) {
-                const int o = (uright[j] ? row * p.pitchR : row * p.pitchL) + (int)uoff[j];   // byte offset within the frame
-                const uint8_t *b = ubase[j];
-                const int ext = uright[j] ? p.extR : p.extL;
-                if (o >= 0 && o + 16 <= ext) {
-                    q.w[j] = *(const u32x4u *)(b + o);
-                } else {                                      // first row left of column 0, or the tail of the last rows
-                    uint32_t w[4] = {0, 0, 0, 0};
-                    for (int i = 0; i < 16; ++i) {
-                        const int oi = o + i;
-                        if (oi >= 0 && oi < ext) w[i >> 2] |= (uint32_t)b[oi] << (8 * (i & 3));
-                    }
-                    q.w[j] = u32x4u{w[0], w[1], w[2], w[3]};
-                }
-            }
+            if (udst[j] >= 0) q.w[j] = fetch(uright[j], ubase[j], uoff[j], row);
+        }
+        if constexpr (O::LVS) {
+            if (lv_wave) { q.v1 = fetch(false, lvbase, lvo1, row); q.v2 = fetch(false, lvbase, lvo2, row); }
         }
         return q;
     };
@@ -206,6 +247,12 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
 #pragma unroll
         for (int j = 0; j < UPL; ++j)
             if (udst[j] >= 0) *(uint4 *)(rows + (buf * 2 + slot) * ROWW + udst[j]) = make_uint4(q.w[j].x, q.w[j].y, q.w[j].z, q.w[j].w);
+        if constexpr (O::LVS) {
+            if (lv_wave)
+                *(uint4 *)(rows + (buf * 2 + slot) * ROWW + lvdst) =
+                    make_uint4(__builtin_amdgcn_perm(q.v2.x, q.v1.x, lvsel), __builtin_amdgcn_perm(q.v2.y, q.v1.y, lvsel),
+                               __builtin_amdgcn_perm(q.v2.z, q.v1.z, lvsel), __builtin_amdgcn_perm(q.v2.w, q.v1.w, lvsel));
+        }
     };
 
     // ---- compute role ----
@@ -255,10 +302,10 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
         // the rows of step r+1 are fetched into registers before the passes of step r and written to the other buffer after them
         Units wn, wo;
         if (more) wn = unit_load(yb + r + 1);
-        if (active) strip_pass_otf<WIN, false>(tL + bo, tR + bo, V, E);
+        if (active) strip_pass_otf<WIN, NG_, DIRECT, false>(tL + bo, tR + bo, V, E);
         if (more) unit_store(wn, (r + 1) & 1, 0);
         if (more_old) wo = unit_load(yb + r + 1 - WIN);
-        if (active && r >= WIN) strip_pass_otf<WIN, true>(tL + bo + ROWW, tR + bo + ROWW, V, E);
+        if (active && r >= WIN) strip_pass_otf<WIN, NG_, DIRECT, true>(tL + bo + ROWW, tR + bo + ROWW, V, E);
         if (more_old) unit_store(wo, (r + 1) & 1, 1);
 
         if (emit && wave_active) {
@@ -307,10 +354,10 @@ static strip_kernel_t otf_entry()
     if constexpr (WIN >= 4 && strip::SG<WIN>::ok && strip::OG<WIN, PNG>::ok) return strip::sad_strip_otf_kernel<WIN, PNG, DIRECT>;
     else return nullptr;
 }
-template <int WIN>
+template <int WIN, bool DIRECT>
 static int otf_lds_one()
 {
-    if constexpr (WIN >= 4 && strip::SG<WIN>::ok && strip::OG<WIN, PNG>::ok) return (4 * strip::OG<WIN, PNG>::ROWW + 2 * 4 * 64 + 64) * 4;
+    if constexpr (WIN >= 4 && strip::SG<WIN>::ok && strip::OG<WIN, PNG>::ok) return (4 * strip::OG<WIN, PNG, DIRECT>::ROWW + 2 * 4 * 64 + 64) * 4;
     else return 0;
 }
 template <int... I>
@@ -321,10 +368,11 @@ strip_kernel_t otf_table(int win, bool direct, Seq<I...>)
     return direct ? td[win - 1] : t[win - 1];
 }
 template <int... I>
-int otf_lds_table(int win, Seq<I...>)
+int otf_lds_table(int win, bool direct, Seq<I...>)
 {
-    static const int t[] = { otf_lds_one<I + 1>()... };
-    return t[win - 1];
+    static const int t[] = { otf_lds_one<I + 1, false>()... };
+    static const int td[] = { otf_lds_one<I + 1, true>()... };
+    return direct ? td[win - 1] : t[win - 1];
 }
 }  // namespace
 
@@ -332,7 +380,7 @@ int otf_lds_table(int win, Seq<I...>)
 #define SADBM_CAT(a, b) SADBM_CAT2(a, b)
 strip_kernel_t SADBM_CAT(otf_part_, SADBM_OTF_PART_NG)(int win, bool direct, int *lds_bytes)
 {
-    if (lds_bytes) *lds_bytes = otf_lds_table(win, MakeSeq<MAXWIN>::type());
+    if (lds_bytes) *lds_bytes = otf_lds_table(win, direct, MakeSeq<MAXWIN>::type());
     return otf_table(win, direct, MakeSeq<MAXWIN>::type());
 }
 

@@ -70,3 +70,35 @@ def test_config2_binary_dots_whole_frame():
     L, R = oracle.rds(2, 1920, 1080, 8, 40, 1)
     got = oa.compute_device(dev(L), dev(R), 9, 64, oa.RAW_LOC).cpu().numpy()
     assert_same(got, oracle.box(L, R, 9, 64, oracle.RAW_LOC), "cfg2 binary")
+
+
+def test_reference_parameters_whole_1080p_and_4k_frames():
+    """winSize 7 / DSR 30 (SAD.cpp:9,11) and D = 32 on whole 1080p and 4K frames: the on-the-fly strip kernels, through the
+    prep pass and reading the frames directly, grey dots and binary dots."""
+    for (W, H, D, seed, binary) in ((1920, 1080, 30, 2, 0), (3840, 2160, 32, 3, 0), (1920, 1080, 30, 12, 1)):
+        L, R = oracle.rds(seed, W, H, 4, 20, binary)
+        exp = oracle.box(L, R, 7, D, oracle.RAW_LOC)
+        ctx = oa.Context(0)
+        got = oa.compute_device(dev(L), dev(R), 7, D, oa.RAW_LOC, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel() == "sad_strip_otf_kernel<7,2>+direct"
+        assert_same(got, exp, "w7 D%d %dx%d" % (D, W, H))
+        L3 = np.stack([L, R, L], -1); R3 = np.stack([R, L, R], -1)       # BGR: channel 0 through the prep pass
+        got = oa.compute_device(dev(L3), dev(R3), 7, D, oa.RAW_LOC, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel() == "sad_strip_otf_kernel<7,2>"
+        assert_same(got, exp, "w7 D%d %dx%d BGR" % (D, W, H))
+
+
+def test_config1_batch_of_256_and_config2_batch_whole_frames():
+    """BASELINE config 1's frame size (384x288, 7x7, D=30) as a batch of 256 distinct pairs (frame groups), and config 2
+    (1920x1080, 9x9, D=64) as a batch of 8: every byte of every frame."""
+    n = 256
+    pairs = [oracle.rds(100 + i, 384, 288, 1 + i % 7, 8 + i % 20, i & 1) for i in range(n)]
+    out = oa.compute_batch_device(dev(np.stack([p[0] for p in pairs])), dev(np.stack([p[1] for p in pairs])), 7, 30).cpu().numpy()
+    for i, (L, R) in enumerate(pairs):
+        assert_same(out[i], oracle.box(L, R, 7, 30), "cfg1 pair %d" % i)
+    pairs = [oracle.rds(20 + i, 1920, 1080, 8 + i, 40 + i, 0) for i in range(8)]
+    ctx = oa.Context(0)
+    out = oa.compute_batch_device(dev(np.stack([p[0] for p in pairs])), dev(np.stack([p[1] for p in pairs])), 9, 64, ctx=ctx).cpu().numpy()
+    assert ctx.last_kernel() == "sad_strip_otf_kernel<9,4>"
+    for i, (L, R) in enumerate(pairs):
+        assert_same(out[i], oracle.box(L, R, 9, 64), "cfg2 pair %d" % i)

@@ -9,14 +9,17 @@
 //                              (not on the strip path: its last band of blocks writes those rows).
 //   2. prep_plane_kernel     : channel 0 of both inputs -> zero-padded single-channel planes in ctx scratch
 //                              (PADL bytes left, PADR right) so the matchers never need bounds checks; for batches on
-//                              the strip matcher several frames side by side per plane (strip_frame_groups).
-//   3. one matcher           : sad_strip_kernel<WIN,NSLM> (sad_strip.inc: 16 columns x 4 disparities per thread, operands
-//                              staged as ready-made dwords in LDS) from 33 disparities up and for small jobs;
-//                              sad_quad_lds_kernel<WIN,KC> (below) otherwise; sad_quad_kernel<WIN> = the same arithmetic
+//                              the strip matcher several frames side by side per plane (strip_frame_groups).  Skipped
+//                              where the on-the-fly strip kernels read single-channel inputs themselves ("+direct").
+//   3. one matcher           : sad_strip_otf_kernel<WIN,NG,DIRECT> (strip_otf_kernels.hip: 16 columns x 4 disparities per
+//                              thread, plain rows staged in LDS, leftover-byte operands packed per thread) up to 64
+//                              disparities; sad_strip_kernel<WIN,NSLM> (sad_strip.inc: the same work split with every operand
+//                              staged as a ready-made dword in LDS) above; sad_quad_lds_kernel<WIN,KC> (quad_kernels.hip) for
+//                              windows below 4 columns and a few 4-wide cases; sad_quad_kernel<WIN> = the same arithmetic
 //                              with operands through L1 (A/B flag); sad_generic_kernel for win > MAXWIN.
 //
-// The quad matcher lives in quad_kernels.hip, the strip matcher in sad_strip.inc / strip_kernels.hip (separate
-// translation units so they compile in parallel); sadbm_internal.hpp holds what they share.
+// The quad matcher lives in quad_kernels.hip, the strip matchers in sad_strip.inc / strip_kernels.hip /
+// strip_otf_kernels.hip (separate translation units so they compile in parallel); sadbm_internal.hpp holds what they share.
 // DESIGN.md section 4 has the measurements behind each choice.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -291,26 +291,32 @@ def main():
             line["latency"] = {"frames": 1, "call_to_sync_ms": round(lat_ms, 4), "matcher_kernel_ms": round(m1 / max(n1, 1), 4),
                                "prep_kernel_ms": round(p1 / max(n1, 1), 4),
                                "value": round(W * H * D / (lat_ms * 1e-3) / 1e9, 1), "unit": "Gdisp-evals/s"}
-            w2, h2, win2, d2, seed2, bg2, fg2, n2 = WORKLOADS["cfg2b_1080p_w9_d128"]
-            n2 = 64
-            fr = [synth.rds(seed2 + 7919 * i, w2, h2, bg2, fg2, 0) for i in range(n2)]
-            l2 = torch.from_numpy(np.stack([f[0] for f in fr])).to(dev)
-            r2 = torch.from_numpy(np.stack([f[1] for f in fr])).to(dev)
-            o2 = torch.empty((n2, h2, w2), dtype=torch.uint8, device=dev)
-            for _ in range(3):
-                oa.compute_batch_device(l2, r2, win2, d2, 0, out=o2, ctx=ctx)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                oa.compute_batch_device(l2, r2, win2, d2, 0, out=o2, ctx=ctx)
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t0
-            ok2 = sha(o2[n2 - 1].cpu().numpy()) == sha(oracle.box(fr[-1][0], fr[-1][1], win2, d2))
-            line["frames_1080p_d128"] = {"frames_per_s": round(n2 * 10 / dt2, 1), "value": round(w2 * h2 * d2 * n2 * 10 / dt2 / 1e9, 1),
-                                         "unit": "Gdisp-evals/s", "workload": "1920x1080, 9x9, D=128, %d frames per step, 10 steps" % n2,
-                                         "last_frame_equals_oracle": ok2}
-            if not ok2:
-                raise SystemExit("bench: 1080p D=128 output differs from the oracle")
+            # other workloads the metric names or the reference defaults to (SAD.cpp:9,11: winSize 7, DSR 30), 10 steps each, the last
+            # frame of the last step compared with the oracle
+            for key, wl, n2 in (("frames_1080p_d128", "cfg2b_1080p_w9_d128", 64), ("frames_1080p_d64", "cfg2_1080p_w9_d64", 64),
+                                ("frames_1080p_w7_d30", "cfg2c_1080p_w7_d30", 64), ("frames_384x288_w7_d30", "cfg1_tsukuba_size_w7_d30", 256)):
+                if wl == args.workload:
+                    continue
+                w2, h2, win2, d2, seed2, bg2, fg2, _n = WORKLOADS[wl]
+                fr = [synth.rds(seed2 + 7919 * i, w2, h2, bg2, fg2, 0) for i in range(n2)]
+                l2 = torch.from_numpy(np.stack([f[0] for f in fr])).to(dev)
+                r2 = torch.from_numpy(np.stack([f[1] for f in fr])).to(dev)
+                o2 = torch.empty((n2, h2, w2), dtype=torch.uint8, device=dev)
+                for _ in range(3):
+                    oa.compute_batch_device(l2, r2, win2, d2, 0, out=o2, ctx=ctx)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    oa.compute_batch_device(l2, r2, win2, d2, 0, out=o2, ctx=ctx)
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t0
+                ok2 = sha(o2[n2 - 1].cpu().numpy()) == sha(oracle.box(fr[-1][0], fr[-1][1], win2, d2))
+                line[key] = {"frames_per_s": round(n2 * 10 / dt2, 1), "value": round(w2 * h2 * d2 * n2 * 10 / dt2 / 1e9, 1),
+                             "unit": "Gdisp-evals/s", "workload": "%dx%d, %dx%d, D=%d, %d frames per step, 10 steps" % (w2, h2, win2, win2, d2, n2),
+                             "kernel": ctx.last_kernel(), "last_frame_equals_oracle": ok2}
+                del l2, r2, o2
+                if not ok2:
+                    raise SystemExit("bench: %s output differs from the oracle" % wl)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

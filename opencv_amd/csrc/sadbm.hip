@@ -492,12 +492,12 @@ int otf_band_rows(int bx, int n_groups, int nvalid, int win, int NG, int n_cus)
 
 // Frames per plane group for the strip matcher: fewest 256-column blocks over the batch, groups at most 16K columns
 // wide; one frame per plane unless grouping saves at least 1.5 % of the blocks.  Wp = frame pitch in columns (x16).
-// gap: columns that must lie between the end of a frame and the next one (15 for the direct-reading kernels, whose
-// 16-byte units must not hold bytes of two frames; Wp then applies to single frames too); *nblocks = 256-column blocks.
-void strip_frame_groups(int cols, int n_pairs, int gap, int *FG, int *Wp, long *nblocks)
+// direct: for the direct-reading kernels, which tell a staging unit's frame from its last column: Wp is a multiple of 16 for
+// single frames too.  *nblocks = 256-column blocks of the batch.
+void strip_frame_groups(int cols, int n_pairs, bool direct, int *FG, int *Wp, long *nblocks)
 {
-    const int wp = (cols + gap + 15) & ~15;
-    *FG = 1; *Wp = gap ? wp : cols;
+    const int wp = (cols + 15) & ~15;
+    *FG = 1; *Wp = direct ? wp : cols;
     *nblocks = (long)n_pairs * ((cols + 255) / 256);
     const int efg = env().strip_fg;
     if (n_pairs < 2 || efg == 1) return;
@@ -598,22 +598,21 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     // as one wide frame whose strips know their frame (sad_strip.inc).
     int FG = 1, Wp = cols;
     long blocksg = 0;
-    if (use_strip) strip_frame_groups(cols, n_pairs, 0, &FG, &Wp, &blocksg);
-    // The on-the-fly form can read single-channel inputs itself: no prep pass (7-8 % of a step at D <= 32, 4 % at 64, and
-    // one launch less per call).  Every frame is then a group of its own: groups of direct-read frames need 15 columns
-    // between frames and measured no faster than single frames (tools/fg_otf.py, profiles/r02e_otf_direct_frame_groups.txt),
-    // so batches whose frame groups save more blocks than the prep pass costs keep the prep pass.  Not for inputs the GPU
-    // reads over PCIe (the host API's zero-copy staging): the matcher reads every byte ~5 times.
-    // (64-thread blocks with windows from 13 columns up: two staging units per lane, the direct variant spills 8-39 VGPRs)
+    if (use_strip) strip_frame_groups(cols, n_pairs, false, &FG, &Wp, &blocksg);
+    // The on-the-fly form reads single-channel inputs itself: no prep pass (7-8 % of a step at D <= 32, 4 % at 64, and one
+    // launch less per call), with the same frame groups (tools/fg_stride.py, profiles/r02f_otf_direct_frame_groups.txt: 64 x
+    // 1080p at 7x7 / D = 30: 0.98 ms against 0.955 + 0.085).  Not for inputs the GPU reads over PCIe (the host API's zero-copy
+    // staging): the matcher reads every byte ~5 times.
+    // (64-thread blocks with windows from 13 columns up: two staging units per lane, the direct variant spills 8-39 VGPRs;
+    // 256-thread blocks with windows up to 13: the plane-reading variant stages the E words of L, which wins back a little more
+    // than the prep pass costs on large jobs -- 64 x 1080p at 9x9 / D = 64: 1.865 + 0.086 ms against 1.969)
     bool direct = use_strip && use_otf && channels == 1 && !ctx->host_inputs && env().direct != 0 && cols + 32 < 65000 &&
                   !(otf_ng == 1 && win >= 13 && env().direct < 0) &&
+                  !(otf_ng == 4 && win <= 13 && (long)n_pairs * nvalid * cols > 4000000L && env().direct < 0) &&
                   (int64_t)need_rows * (pitchL > pitchR ? pitchL : pitchR) < 0x7ff00000LL;
     if (direct) {
-        int fgd = 1, wpd = cols; long blocksd = 0;
-        strip_frame_groups(cols, env().direct == 1 ? n_pairs : 1, 15, &fgd, &wpd, &blocksd);   // SADBM_DIRECT=1: direct-read groups too (tests)
-        if (env().direct < 0) blocksd = (long)n_pairs * ((cols + 255) / 256);
-        if (env().direct < 0 && (double)blocksd > (double)blocksg * (otf_ng <= 2 ? 1.06 : 1.03)) direct = false;
-        else { FG = fgd; Wp = wpd; sk = pick_strip_otf_kernel(win, otf_ng, true, &otf_lds); }
+        strip_frame_groups(cols, n_pairs, true, &FG, &Wp, &blocksg);
+        sk = pick_strip_otf_kernel(win, otf_ng, true, &otf_lds);
     }
     if (use_strip && !direct && ((size_t)(PADL + (size_t)(FG - 1) * Wp + cols + PADR + 127) & ~(size_t)127) * (size_t)need_rows > 0x7ff00000u) {
         FG = 1; Wp = cols;                                    // the strip matcher addresses the R plane with 32-bit offsets

@@ -168,9 +168,10 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
 
     // ---- staging role of this lane: units tid (+ nthr) of every row image (16 bytes of LP, or of RP[c]) ----
     constexpr int UPL = O::UPL;
-    // DIRECT: a unit belongs to the frame of its LAST byte: frames are Wp >= cols + 15 columns apart, so whatever precedes
-    // that frame's column 0 inside the unit lies in the gap behind the previous frame (only zeroed columns read it); the
-    // unit's bytes left of column 0 come from the row above, and reach only slots that never compete (k > column).
+    // DIRECT: a unit belongs to the frame of its LAST byte (frames are Wp = a multiple of 16 >= cols columns apart).  Only the units
+    // of R's byte-shifted copies can start in the previous frame: the c bytes before column 0 of copy c.  They come from the row
+    // above instead -- nobody needs either: class c holds the disparities k >= c, and a competing slot reads R columns
+    // x + j - k <= cols - 2 - c of its own frame, or >= 0 (k <= x).
     uint32_t uoff[UPL]; int udst[UPL]; bool uright[UPL]; const uint8_t *ubase[UPL];
 #pragma unroll
     for (int j = 0; j < UPL; ++j) {

@@ -326,17 +326,25 @@ def compute_band_device(left_band, right_band, frame_rows, row0, rows_out, winSi
 
 
 def compute_batch_device(left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags=0, out=None, ctx=None):
-    """N pairs at once: left/right are NxHxW (or NxHxWxC) contiguous uint8 CUDA tensors."""
+    """N pairs at once: left/right are NxHxW (or NxHxWxC) uint8 CUDA tensors with contiguous pixels; views with a row pitch
+    and a frame stride (crops of a larger batch) are passed through when left and right share them, anything else is copied."""
     import torch
     L = load_library()
     if left.dim() == 3:
         left = left.unsqueeze(-1)
         right = right.unsqueeze(-1)
-    left = left.contiguous()
-    right = right.contiguous()
     if left.shape != right.shape:
         raise SadbmError(-3, "batched left/right must have equal shapes")
     n, rows, cols, ch = left.shape
+
+    def _pitched(t):
+        return (t.stride(3) == 1 or ch == 1) and (cols <= 1 or t.stride(2) == ch) and (rows <= 1 or t.stride(1) >= cols * ch) and \
+               (n <= 1 or t.stride(0) >= rows * (t.stride(1) if rows > 1 else cols * ch))
+    if not (_pitched(left) and _pitched(right) and (rows <= 1 or left.stride(1) == right.stride(1)) and (n <= 1 or left.stride(0) == right.stride(0))):
+        left = left.contiguous()
+        right = right.contiguous()
+    pitch_in = left.stride(1) if rows > 1 else cols * ch
+    stride_in = left.stride(0) if n > 1 else rows * pitch_in
     dev = left.device.index or 0
     ctx = ctx or _ctx_for(dev)
     if out is None:
@@ -345,7 +353,7 @@ def compute_batch_device(left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR,
           or (cols > 1 and out.stride(2) != 1)):
         raise SadbmError(-3, "out must be an NxHxW uint8 tensor on the inputs' device with unit column stride")
     with torch.cuda.device(dev):
-        _check(L.sadbm_compute_batch_device(ctx.handle, left.data_ptr(), right.data_ptr(), cols * ch, rows * cols * ch, n,
+        _check(L.sadbm_compute_batch_device(ctx.handle, left.data_ptr(), right.data_ptr(), pitch_in, stride_in, n,
                                             rows, cols, ch, int(winSize), int(DSR), int(flags), out.data_ptr(),
                                             out.stride(1), out.stride(0), _stream_ptr(dev)))   # pitched views allowed
     return out

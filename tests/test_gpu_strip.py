@@ -239,11 +239,23 @@ def test_direct_reads_of_caller_images(win, D, monkeypatch):
 
 @pytest.mark.parametrize("W", [384, 203, 16, 640])
 def test_direct_reads_with_frame_groups(W, monkeypatch):
-    """SADBM_DIRECT=1: direct reads also where frames share a group (not the default: measured no faster than single frames).
-    Frames lie 15+ columns apart in the group's column space, a 16-byte unit holds bytes of one frame only."""
+    """Direct reads where frames share a group: frames lie a multiple of 16 columns apart in the group's column space; a staging
+    unit that starts in the previous frame (the c bytes before column 0 of R's copy c) is read from the row above instead --
+    no competing slot needs either.  Widths that are and are not multiples of 16 / 256, cropped batch views (row pitch and
+    frame stride passed through), SADBM_DIRECT=1 (also 64-thread blocks with wide windows)."""
+    import torch
+    n, H = 9, 38
+    for win, D in ((7, 30), (9, 64)):
+        Ls, Rs = zip(*[noise_pair(W + 13 * i + win, H, W, shift=min(2 + i, W - 1)) for i in range(n)])
+        bl = torch.full((n, H + 2, W + 21), 99, dtype=torch.uint8, device="cuda"); br = torch.full((n, H + 2, W + 21), 77, dtype=torch.uint8, device="cuda")
+        bl[:, 1:1 + H, 5:5 + W] = dev(np.stack(Ls)); br[:, 1:1 + H, 5:5 + W] = dev(np.stack(Rs))
+        ctx = oa.Context(0)
+        out = oa.compute_batch_device(bl[:, 1:1 + H, 5:5 + W], br[:, 1:1 + H, 5:5 + W], win, D, 0, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel() == strip_kernel_name(win, D) + "+direct"
+        for i in range(n):
+            assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), ("view", W, win, D, i)
     monkeypatch.setenv("SADBM_DIRECT", "1")
     oa.reload_env()
-    n, H = 9, 38
     for win, D in ((7, 30), (9, 64), (13, 12)):
         Ls, Rs = zip(*[noise_pair(W + 11 * i + win, H, W, shift=min(3 + i, W - 1), binary=bool(i & 1)) for i in range(n)])
         ctx = oa.Context(0)

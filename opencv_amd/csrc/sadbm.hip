@@ -409,7 +409,7 @@ struct EnvKnobs {
     int prep_bx = 0;             // SADBM_PREP_BX    block width of prep_plane_kernel (0 = choose)
     int kc = 0;                  // SADBM_KC         disparities per thread of the quad matcher (0 = choose)
     int quad_half = -1;          // SADBM_QUAD_HALF  half-width (128-thread) blocks of the quad matcher: -1 choose, 0 never, 1 always
-    int otf = -1;                // SADBM_OTF        on-the-fly form of the strip matcher (strip_otf_kernels.hip): -1 choose, 0 never, 1 whenever D <= 64
+    int otf = -1;                // SADBM_OTF        on-the-fly form of the strip matcher (strip_otf_kernels.hip): -1 choose, 0 never, 1 whenever D <= 128
     int otf_ng = 0;              // SADBM_OTF_NG     its disparity groups per block: 0 choose (fewest that cover D), 1, 2 or 4
     int trace = 0;               // SADBM_TRACE      1: one line per matcher launch on stderr (kernel, grid shape)
     int direct = -1;             // SADBM_DIRECT     on-the-fly form reading the caller's 1-channel images itself (no prep pass): -1 choose, 0 never, 1 whenever possible
@@ -428,7 +428,7 @@ EnvKnobs read_env()
     k.otf = geti("SADBM_OTF", -1); if (k.otf < 0 || k.otf > 1) k.otf = -1;
     k.trace = geti("SADBM_TRACE", 0);
     k.direct = geti("SADBM_DIRECT", -1); if (k.direct < 0 || k.direct > 1) k.direct = -1;
-    k.otf_ng = geti("SADBM_OTF_NG", 0); if (k.otf_ng != 1 && k.otf_ng != 2 && k.otf_ng != 4) k.otf_ng = 0;
+    k.otf_ng = geti("SADBM_OTF_NG", 0); if (k.otf_ng != 1 && k.otf_ng != 2 && k.otf_ng != 4 && k.otf_ng != 8) k.otf_ng = 0;
     if (const char *e = getenv("SADBM_ZEROCOPY_BYTES")) k.zc_bytes = atol(e);
     return k;
 }
@@ -537,7 +537,10 @@ bool strip_is_default(int win, int D, int cols, int rows, int n_pairs)
 bool otf_is_default(int win, int D, int cols, int rows, int n_pairs)
 {
     (void)cols; (void)rows; (void)n_pairs;
-    return D <= 64 && (win >= 5 || D <= 16);
+    // 65-128 disparities, not a multiple of 16, windows whose keys have room for poisoned sums (SG::POISON): 512-thread blocks
+    // of the on-the-fly form against the staged kernel's masked argmin, 32 x 1080p at 7x7 / D = 100: 1.73 against 1.89 ms
+    if (D > 64) return D <= 128 && D % 16 != 0 && win >= 5 && win <= 11 && win != 10;
+    return win >= 5 || D <= 16;
 }
 
 // The whole device pipeline for n_pairs frames (or one band).  Input rows available: rows_in; output
@@ -582,9 +585,9 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     strip_kernel_t sk = (win <= MAXWIN && cols < 65000) ? pick_strip_kernel(win, strip::NS + strip_ng) : nullptr;
     // short searches: the on-the-fly form (blocks of 1, 2 or 4 groups of 16 disparities, strip_otf_kernels.hip)
     int otf_lds = 0;
-    int otf_ng = D <= 16 ? 1 : D <= 32 ? 2 : 4;
+    int otf_ng = D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : 8;
     if (env().otf_ng > otf_ng) otf_ng = env().otf_ng;
-    strip_kernel_t sk_otf = (D <= 64 && win <= MAXWIN && cols < 65000 && env().otf != 0) ? pick_strip_otf_kernel(win, otf_ng, false, &otf_lds) : nullptr;
+    strip_kernel_t sk_otf = (D <= 128 && win <= MAXWIN && cols < 65000 && env().otf != 0) ? pick_strip_otf_kernel(win, otf_ng, false, &otf_lds) : nullptr;
     const bool use_otf = sk_otf != nullptr && (env().otf == 1 || otf_is_default(win, D, cols, nvalid, n_pairs));
     if (use_otf) { sk = sk_otf; strip_ng = otf_ng; }
     if (sk && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL | SADBM_KERNEL_QUAD))) {
@@ -608,7 +611,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     // than the prep pass costs on large jobs -- 64 x 1080p at 9x9 / D = 64: 1.865 + 0.086 ms against 1.969)
     bool direct = use_strip && use_otf && channels == 1 && !ctx->host_inputs && env().direct != 0 && cols + 32 < 65000 &&
                   !(otf_ng == 1 && win >= 13 && env().direct < 0) &&
-                  !(otf_ng == 4 && win <= 13 && (long)n_pairs * nvalid * cols > 4000000L && env().direct < 0) &&
+                  !(otf_ng >= 4 && win <= 13 && (long)n_pairs * nvalid * cols > 4000000L && env().direct < 0) &&
                   (int64_t)need_rows * (pitchL > pitchR ? pitchL : pitchR) < 0x7ff00000LL;
     if (direct) {
         strip_frame_groups(cols, n_pairs, true, &FG, &Wp, &blocksg);
@@ -672,7 +675,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         // rows per block: a block is 64*NG threads and two blocks fit a CU only up to NG = 8, so the grid is a few
         // hundred large blocks and its quantisation matters.  Minimise rounds x steps-per-block over band heights
         // that fill whole rounds of block slots (a round whose CUs hold a single block runs ~0.65 as long).
-        int TY = use_otf ? otf_band_rows(bx, n_groups, nvalid, win, q.NG, ctx->cus) : strip_band_rows(bx, n_groups, nvalid, win, q.NG, ctx->cus);
+        int TY = (use_otf && q.NG <= 4) ? otf_band_rows(bx, n_groups, nvalid, win, q.NG, ctx->cus) : strip_band_rows(bx, n_groups, nvalid, win, q.NG, ctx->cus);
         q.TY = TY;
         const int NSL = strip::NS + q.NG;
         int PR = 0, ROWW = 0;

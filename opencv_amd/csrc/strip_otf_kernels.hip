@@ -1,5 +1,7 @@
-// strip_otf_kernels.hip -- the strip matcher for short searches ("on-the-fly" form): blocks of NG = 1, 2 or 4 groups of 16
-// disparities (64, 128 or 256 threads).  Compiled once per NG (-DSADBM_OTF_PART_NG=1 / 2 / 4) so the builds run in parallel.
+// strip_otf_kernels.hip -- the strip matcher for short searches ("on-the-fly" form): blocks of NG = 1, 2, 4 or 8 groups of 16
+// disparities (64 ... 512 threads).  Compiled once per NG (-DSADBM_OTF_PART_NG=1 / 2 / 4 / 8) so the builds run in parallel.
+// (NG = 8 serves searches of 65-128 disparities that are not a multiple of 16, where the poisoned sums below beat the staged
+// kernel's masked argmin; at multiples of 16 and at NG = 16 the staged kernel is as fast or faster: profiles/r02g_otf_wide_searches.txt.)
 //
 // Same arithmetic as getDisparity()/sub_kernel() of /root/reference/SAD.cpp:13-61 and the same work split, window
 // decomposition, running sums, key phase and finalisation as sad_strip_kernel (sad_strip.inc): a thread owns 16 columns x 4
@@ -16,7 +18,7 @@
 #include "sadbm_internal.hpp"
 
 #ifndef SADBM_OTF_PART_NG
-#error "compile with -DSADBM_OTF_PART_NG=1, 2 or 4"
+#error "compile with -DSADBM_OTF_PART_NG=1, 2, 4 or 8"
 #endif
 
 namespace sadbm_detail {
@@ -346,6 +348,7 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
 strip_kernel_t otf_part_1(int win, bool direct, int *lds_bytes);
 strip_kernel_t otf_part_2(int win, bool direct, int *lds_bytes);
 strip_kernel_t otf_part_4(int win, bool direct, int *lds_bytes);
+strip_kernel_t otf_part_8(int win, bool direct, int *lds_bytes);
 
 namespace {
 constexpr int PNG = SADBM_OTF_PART_NG;
@@ -389,7 +392,8 @@ strip_kernel_t SADBM_CAT(otf_part_, SADBM_OTF_PART_NG)(int win, bool direct, int
 strip_kernel_t pick_strip_otf_kernel(int win, int ng, bool direct, int *lds_bytes)
 {
     if (win < 1 || win > MAXWIN) return nullptr;
-    return ng == 1 ? otf_part_1(win, direct, lds_bytes) : ng == 2 ? otf_part_2(win, direct, lds_bytes) : ng == 4 ? otf_part_4(win, direct, lds_bytes) : nullptr;
+    return ng == 1 ? otf_part_1(win, direct, lds_bytes) : ng == 2 ? otf_part_2(win, direct, lds_bytes) : ng == 4 ? otf_part_4(win, direct, lds_bytes)
+         : ng == 8 ? otf_part_8(win, direct, lds_bytes) : nullptr;
 }
 #endif
 

@@ -145,6 +145,23 @@ def test_strip_every_window_instantiation(win, form):
         assert np.array_equal(got, oracle.box(L, R, win, D, oracle.RAW_LOC)), (win, D)
 
 
+@pytest.mark.parametrize("win", list(range(4, 26)))
+def test_on_the_fly_form_512_thread_blocks_every_window(win, monkeypatch):
+    """SADBM_OTF=1: the on-the-fly form wherever it is instantiated, i.e. up to 128 disparities (512-thread blocks; by default only
+    for narrow windows at 65-128 disparities that are not a multiple of 16), plane-reading and direct variants."""
+    monkeypatch.setenv("SADBM_OTF", "1")
+    L, R = noise_pair(1700 + win, 49, 531, shift=11)
+    for D in (65, 100, 128):
+        exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
+        for direct in ("0", "1"):
+            monkeypatch.setenv("SADBM_DIRECT", direct)
+            oa.reload_env()
+            ctx = oa.Context(0)
+            got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC, ctx=ctx).cpu().numpy()
+            assert ctx.last_kernel() == "sad_strip_otf_kernel<%d,8>%s" % (win, "+direct" if direct == "1" else "")
+            assert np.array_equal(got, exp), (win, D, direct)
+
+
 @pytest.mark.parametrize("shape,pairs", [((40, 203), 5), ((33, 640), 3), ((25, 100), 7), ((20, 16), 9), ((30, 250), 2), ((22, 1242), 4),
                                          ((12, 37), 33)])
 def test_strip_frame_groups(shape, pairs, monkeypatch, form):

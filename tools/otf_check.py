@@ -30,7 +30,7 @@ if mode in ("parity", "all"):
     bad_total = 0
     rng = np.random.default_rng(5)
     ctx = oa.Context(0)
-    for win, ngf, D in [(w, n, d) for w in range(4, 26) for (n, ds) in ((None, (1, 5, 16, 17, 30, 32)), (2, (3, 16)), (4, (7, 31, 33, 50, 64))) for d in ds]:
+    for win, ngf, D in [(w, n, d) for w in range(4, 26) for (n, ds) in ((None, (1, 5, 16, 17, 30, 32)), (2, (3, 16)), (4, (7, 31, 33, 50, 64)), (8, (40, 70, 100, 128))) for d in ds]:
         setenv(1, ngf)
         if True:
             for (H, W) in ((win + 9, 203), (40, 517), (33, 260)):

@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
     const bool active = (fr < nf) && (xs < ocols) && (kb < p.D) && (kb <= xs + 15);
     const bool diag = active && (kb + 12 > xs);
     const bool mask_d = G::POISON == 0 && __any(active && (kb + 12 >= p.D));   // see SG::POISON
-    const bool any_diag = __any(diag);
+    const bool any_diag = G::EPOISON == 0 && __any(diag);     // see SG::EPOISON
     const EmitCtx ec = {kb, c, diag, {false, kb + 4 >= p.D, kb + 8 >= p.D, kb + 12 >= p.D}};
     const bool wave_active = __any(active);
     const bool wave_full = __all(active);
@@ -285,6 +285,20 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
         for (int n = 0; n < NV; ++n) V[t][n] = v0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { E[t][i][0] = 0; E[t][i][1] = 0; }
+    }
+    if constexpr (G::EPOISON != 0) {
+        // diagonal lanes (xs == 16 g): slot (t, quad i, column offset a) never competes iff 4 (i - t) + a < c; slots with k >= D
+        // are poisoned through V already (both together would overflow the key)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i <= t; ++i)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const bool never = diag && kb + 4 * t < p.D && (i < t || a < c);
+                    const uint32_t pe = (G::minus(a) ? (65536u - G::EPOISON) : G::EPOISON) << (16 * (a & 1));
+                    E[t][i][a >> 1] += never ? pe : 0u;
+                }
     }
 
     unit_store(unit_load(yb), 0, 0);

@@ -98,7 +98,9 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
 
 /* Device-resident getDisparity: dL/dR/dOut are device pointers on ctx's device; asynchronous on
  * `stream` (a hipStream_t passed as void*; NULL = the device's default stream, as in HIP).  channels in {1,3,4}
- * (channel 0 is used, SAD.cpp:19-20). */
+ * (channel 0 is used, SAD.cpp:19-20).  dOut must not overlap dL or dR (the reference writes a fresh Mat, SAD.cpp:31): the
+ * matcher may read the inputs in place while it writes the output.  Only the bytes of the images themselves are read
+ * (rows * pitch is not assumed readable beyond the last row's last column). */
 int sadbm_compute_device(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_t *dR,
                          int64_t pitchR, int rows, int cols, int channels, int win, int max_disp,
                          uint32_t flags, uint8_t *dOut, int64_t out_pitch, void *stream);

@@ -411,6 +411,7 @@ struct EnvKnobs {
     int quad_half = -1;          // SADBM_QUAD_HALF  half-width (128-thread) blocks of the quad matcher: -1 choose, 0 never, 1 always
     int otf = -1;                // SADBM_OTF        on-the-fly form of the strip matcher (strip_otf_kernels.hip): -1 choose, 0 never, 1 whenever D <= 128
     int otf_ng = 0;              // SADBM_OTF_NG     its disparity groups per block: 0 choose (fewest that cover D), 1, 2 or 4
+    int tail = -1;               // SADBM_TAIL       on-the-fly kernels: units per XCD split into half-height blocks at the end of the launch (-1 choose, 0 none)
     int trace = 0;               // SADBM_TRACE      1: one line per matcher launch on stderr (kernel, grid shape)
     int direct = -1;             // SADBM_DIRECT     on-the-fly form reading the caller's 1-channel images itself (no prep pass): -1 choose, 0 never, 1 whenever possible
     long zc_bytes = 1 << 20;     // SADBM_ZEROCOPY_BYTES  host API: inputs up to this size are read by the GPU from pinned host memory
@@ -426,6 +427,7 @@ EnvKnobs read_env()
     k.kc = geti("SADBM_KC", 0); if (k.kc != 8 && k.kc != 16) k.kc = 0;
     k.quad_half = geti("SADBM_QUAD_HALF", -1); if (k.quad_half < 0 || k.quad_half > 1) k.quad_half = -1;
     k.otf = geti("SADBM_OTF", -1); if (k.otf < 0 || k.otf > 1) k.otf = -1;
+    k.tail = geti("SADBM_TAIL", -1); if (k.tail < -1) k.tail = -1;
     k.trace = geti("SADBM_TRACE", 0);
     k.direct = geti("SADBM_DIRECT", -1); if (k.direct < 0 || k.direct > 1) k.direct = -1;
     k.otf_ng = geti("SADBM_OTF_NG", 0); if (k.otf_ng != 1 && k.otf_ng != 2 && k.otf_ng != 4 && k.otf_ng != 8) k.otf_ng = 0;
@@ -686,11 +688,23 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         q.FG = FG; q.Wp = Wp; q.npairs = n_pairs;
         q.rows_out = strip_zeroes ? rows_out : nvalid;
         const long nblocks = (long)q.nbx * q.nby * q.ngroups;
-        if (nblocks > 0x7ffffff0L) return SADBM_E_SIZE;
-        dim3 g((unsigned)((nblocks + 7) & ~7L));               // 1-D, XCD-aware order decoded in the kernel
+        if (nblocks > 0x3ffffff0L) return SADBM_E_SIZE;
+        q.tail = 0;
+        long chunk_units = (nblocks + 7) / 8;                  // per XCD
+        if (use_otf && env().tail != 0 && TY >= (env().tail > 0 ? 1 : 8)) {
+            // on-the-fly kernels: the last round of block slots of every XCD runs as half-height blocks: 64 x 1080p at 7x7 / D = 30
+            // -3.7 %, 32 x 4K -1.5 %, config 2 -1 % (SADBM_TAIL sweep: one round is the best size); jobs of fewer than three rounds
+            // gain nothing or lose 1-2 % to the extra warm-up rows, they keep whole blocks
+            const long slots_xcd = (long)(ctx->cus / 8 > 0 ? ctx->cus / 8 : 1) * (16 / q.NG);
+            long t = env().tail > 0 ? env().tail : slots_xcd;
+            if (t > chunk_units / 2) t = chunk_units / 2;
+            if (env().tail < 0 && chunk_units < 3 * slots_xcd) t = 0;
+            q.tail = (int)t;
+        }
+        dim3 g((unsigned)(8 * (chunk_units + q.tail)));         // 1-D, XCD-aware order decoded in the kernel
         if (env().trace)
-            fprintf(stderr, "sadbm: strip%s win %d D %d NG %d direct %d  %dx%d x%d  FG %d Wp %d  bx %d nby %d groups %d TY %d  lds %zu\n", use_otf ? "_otf" : "",
-                    win, D, q.NG, (int)direct, cols, nvalid, n_pairs, FG, Wp, q.nbx, q.nby, q.ngroups, TY, lds);
+            fprintf(stderr, "sadbm: strip%s win %d D %d NG %d direct %d  %dx%d x%d  FG %d Wp %d  bx %d nby %d groups %d TY %d  tail %d  lds %zu\n", use_otf ? "_otf" : "",
+                    win, D, q.NG, (int)direct, cols, nvalid, n_pairs, FG, Wp, q.nbx, q.nby, q.ngroups, TY, q.tail, lds);
         hipLaunchKernelGGL(sk, g, dim3(64 * q.NG), lds, st, q);
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), use_otf ? "sad_strip_otf_kernel<%d>" : "sad_strip_kernel<%d>", win);
         if (use_otf) snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_strip_otf_kernel<%d,%d>%s", win, otf_ng, direct ? "+direct" : "");

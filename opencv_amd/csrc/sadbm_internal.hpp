@@ -45,6 +45,7 @@ struct SParams {
     int nbx, nby, ngroups;    // column blocks, row bands, frame groups: the launch is 1-D over their product (padded to 8)
     int FG, Wp, npairs;       // a group = FG frames side by side in one plane, Wp columns apart (Wp % 16 == 0); total frames
     int rows_out;             // output rows [nvalid, rows_out) are zero-filled by the blocks of the last band
+    int tail;                 // sad_strip_otf_kernel: the last `tail` (column block, band, group) units of every XCD's chunk run as two half-height blocks
     // direct variant of sad_strip_otf_kernel only: the caller's images (single channel), frames in_stride bytes apart; every
     // byte [0, ext) from a frame's first byte is readable (ext = (rows read - 1) * pitch + cols < 2^31)
     const uint8_t *dL, *dR;

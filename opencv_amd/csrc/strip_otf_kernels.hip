@@ -149,16 +149,28 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
     uint32_t *cells = smem + 4 * ROWW;                        // [2 parities][4 a][64 quads]
     uint32_t *fxs = cells + 2 * 4 * 64;                       // [64] frame / column of each output quad of the block
 
-    // 1-D XCD-aware launch, as sad_strip_kernel
-    const int chunk = (int)(gridDim.x >> 3);
-    const int vb = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (vb >= p.nbx * p.nby * p.ngroups) return;              // grid padded to a multiple of 8 (block-uniform exit)
+    // 1-D XCD-aware launch, as sad_strip_kernel: XCD j (= blockIdx & 7) walks the contiguous chunk j of the (column block, band,
+    // group) order.  The last p.tail units of every chunk are split into two half-height blocks each: the blocks that run
+    // last are then half as long, and so is the stretch at the end of the launch in which CUs run dry one after another.
+    const int chunk = (int)(gridDim.x >> 3);                   // blocks per XCD: chunk_units + tail
+    const int chunk_units = chunk - p.tail;
+    const int q = (int)(blockIdx.x >> 3);
+    int vb = (int)(blockIdx.x & 7) * chunk_units, half = -1;
+    if (q < chunk_units - p.tail) vb += q;
+    else { const int h = q - (chunk_units - p.tail); vb += chunk_units - p.tail + (h >> 1); half = h & 1; }
+    if (vb >= p.nbx * p.nby * p.ngroups) return;              // chunks are padded (block-uniform exit)
     const int bxi = vb % p.nbx, tb = vb / p.nbx, byi = tb % p.nby, pz = tb / p.nby;
     const int XB = bxi * XBW;
     const int nf = min(p.FG, p.npairs - pz * p.FG);
     if (XB >= (nf - 1) * p.Wp + p.W) return;                  // block-uniform
-    const int yb = byi * p.TY;
-    const int ny = min(p.TY, p.nvalid - yb);
+    int yb = byi * p.TY;
+    int ny = min(p.TY, p.nvalid - yb);
+    if (half >= 0) {
+        const int h0 = (ny + 1) >> 1;
+        if (half == 0) ny = h0; else { yb += h0; ny -= h0; }
+        if (ny <= 0) return;                                  // block-uniform
+    }
+    const bool last_band = yb + ny >= p.nvalid;               // writes the zero frame below the computed rows
     const uint8_t *Lbase = p.Lrow0 + (int64_t)pz * p.pair_stride;   // padded planes (not DIRECT)
     const int ocols = p.W - p.win;
 
@@ -342,7 +354,7 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
         strip_finalize<WIN>(p, cells + ((nsteps & 1) ^ 1) * 256, pz * p.FG, fxs[lane], yb + nsteps - WIN, lane, ocols, false);
 
     // the zero frame below the computed rows (SAD.cpp:31,34), written by the blocks of the last band
-    if (byi == p.nby - 1) {
+    if (last_band) {
         const uint32_t fx = fxs[lane];
         const int x0 = (int)(fx & 0xFFFFu);
         if (x0 < p.W) {

@@ -294,3 +294,19 @@ def test_direct_is_not_used_for_colour_or_host_mapped_inputs():
     big = np.ascontiguousarray(np.tile(L[:, :, 0], (3, 3))); bigr = np.ascontiguousarray(np.tile(R[:, :, 0], (3, 3)))
     assert np.array_equal(oa.get_disparity_host(big, bigr, 7, 30, ctx=ctx), oracle.box(big, bigr, 7, 30))
     assert ctx.last_kernel() == "sad_strip_otf_kernel<7,2>+direct"        # staged on the device first: read directly
+
+
+@pytest.mark.parametrize("tail", ["0", "1", "5", "100000"])
+def test_half_height_blocks_at_the_end_of_the_launch(tail, monkeypatch):
+    """SADBM_TAIL: the last units of every XCD's share of an on-the-fly launch run as two half-height blocks (by default only on
+    jobs of three rounds of block slots and more) -- forced here on small batches: odd band heights, one-row bands, a band
+    shorter than the others, frame groups, the zero frame below the computed rows."""
+    monkeypatch.setenv("SADBM_TAIL", tail)
+    for ty in ("0", "1", "7"):
+        monkeypatch.setenv("SADBM_STRIP_TY", ty)
+        oa.reload_env()
+        for (H, W, n, win, D) in ((47, 530, 5, 7, 30), (30, 384, 9, 9, 64), (26, 270, 3, 15, 12)):
+            Ls, Rs = zip(*[noise_pair(H + 3 * i + win, H, W, shift=min(2 + i, D - 1)) for i in range(n)])
+            out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, 0).cpu().numpy()
+            for i in range(n):
+                assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), (tail, ty, H, W, win, D, i)

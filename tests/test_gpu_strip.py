@@ -310,3 +310,20 @@ def test_half_height_blocks_at_the_end_of_the_launch(tail, monkeypatch):
             out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, 0).cpu().numpy()
             for i in range(n):
                 assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), (tail, ty, H, W, win, D, i)
+
+
+@pytest.mark.parametrize("win", [5, 6, 7, 9, 11, 8, 13, 16, 17, 25])
+def test_largest_costs_with_poisoned_sums(win):
+    """All-255 against all-0 (every absolute difference 255: the largest cost a window can have) and the reverse, checkerboards of
+    the two, at D = 30 / 64 / 100: the poisoned sums of never-competing slots (k >= D, k > column) must stay above every real
+    cost without overflowing their 16-bit fields -- at the left border, where both kinds of slot meet."""
+    H, W = win + 6, 300
+    big = np.full((H, W), 255, np.uint8)
+    zero = np.zeros((H, W), np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    chk = np.where((xx // 3 + yy) & 1, 255, 0).astype(np.uint8)
+    for D in (30, 64, 100):
+        for L, R in ((big, zero), (zero, big), (chk, 255 - chk), (big, chk)):
+            exp = oracle.literal(L, R, win, D, oracle.RAW_LOC)
+            got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC).cpu().numpy()
+            assert np.array_equal(got, exp), (win, D, np.argwhere(got != exp)[:4])

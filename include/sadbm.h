@@ -189,6 +189,14 @@ int sadbm_compute_device_static(int device, const uint8_t *dL, int64_t pitchL, c
 const char *sadbm_last_kernel_name(const sadbm_ctx *ctx);
 int sadbm_profile_begin(sadbm_ctx *ctx, int max_launches);
 int sadbm_profile_end(sadbm_ctx *ctx, int *n_launches, float *matcher_ms_total, float *prep_ms_total);
+/* What a call on n_pairs whole frames (contiguous, device-resident) would launch, without touching a GPU (no reference
+ * counterpart; for integrators sizing their batches and for the CPU-only tests of the launch policy): one line of
+ * key=value fields -- matcher family, kernel, threads per block, frame groups (FG frames side by side, Wp columns apart),
+ * 256-column blocks per group row (bx), rows per block (TY), bands (nby), blocks, half-height tail units per XCD, dynamic
+ * LDS bytes, scratch bytes the context would hold, whether the plane-preparation pass runs.  cus = compute units of the
+ * device (<= 0: 256, an MI355X).  Returns SADBM_OK or the SADBM_E_* code the call itself would return for these arguments. */
+int sadbm_plan_describe(int rows, int cols, int channels, int n_pairs, int win, int max_disp, uint32_t flags, int cus,
+                        char *text, int text_len);
 /* The tuning knobs of INTEGRATION.md are read from the environment once, at the first call; this re-reads them. */
 void sadbm_reload_env(void);
 

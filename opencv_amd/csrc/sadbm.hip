@@ -545,6 +545,103 @@ bool otf_is_default(int win, int D, int cols, int rows, int n_pairs)
     return win >= 5 || D <= 16;
 }
 
+// What run_pipeline decides before it touches the GPU: which matcher family, and for the strip family the kernel form, the
+// frame groups, whether the inputs are read in place, the scratch planes and the grid.  No HIP calls: sadbm_plan_describe()
+// exposes it, and the CPU-only tests check the policy and its invariants through that.
+struct StripPlan {
+    bool use_strip = false, use_otf = false, direct = false, strip_zeroes = false;
+    int ng = 0;                           // groups of 16 disparities per block (block = 64 ng threads)
+    int FG = 1, Wp = 0, n_groups = 0, vcols = 0, pitch = 0;
+    size_t plane_bytes = 0, planes_need = 0;
+    int bx = 0, TY = 0, nby = 0, tail = 0;
+    long nblocks = 0;
+    size_t lds = 0;
+    strip_kernel_t kernel = nullptr;
+};
+StripPlan plan_strip(int cus, bool host_inputs, int64_t pitchL, int64_t pitchR, int n_pairs, int rows_out, int nvalid, int cols,
+                     int channels, int win, int D, uint32_t flags)
+{
+    StripPlan sp;
+    const int need_rows = nvalid + win - 1;
+    // matcher choice: SADBM_KERNEL_STRIP / SADBM_KERNEL_QUAD force one; env SADBM_MATCHER=strip|quad overrides the default
+    bool use_strip = false;
+    int strip_ng = D <= 64 ? 4 : D <= 128 ? 8 : 16;          // disparity groups of 16 per block (multiple of 4)
+    strip_kernel_t sk = (win <= MAXWIN && cols < 65000) ? pick_strip_kernel(win, strip::NS + strip_ng) : nullptr;
+    // short searches: the on-the-fly form (blocks of 1, 2 or 4 groups of 16 disparities, strip_otf_kernels.hip)
+    int otf_lds = 0;
+    int otf_ng = D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : 8;
+    if (env().otf_ng > otf_ng) otf_ng = env().otf_ng;
+    strip_kernel_t sk_otf = (D <= 128 && win <= MAXWIN && cols < 65000 && env().otf != 0) ? pick_strip_otf_kernel(win, otf_ng, false, &otf_lds) : nullptr;
+    const bool use_otf = sk_otf != nullptr && (env().otf == 1 || otf_is_default(win, D, cols, nvalid, n_pairs));
+    if (use_otf) { sk = sk_otf; strip_ng = otf_ng; }
+    if (sk && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL | SADBM_KERNEL_QUAD))) {
+        use_strip = (flags & SADBM_KERNEL_STRIP) != 0 || use_otf || strip_is_default(win, D, cols, nvalid, n_pairs);
+        if (env().matcher && !(flags & SADBM_KERNEL_STRIP)) use_strip = env().matcher == 1;
+    }
+
+    // Scratch planes.  The quad / generic matchers get one padded plane pair per frame.  The strip matcher works on
+    // 256-column blocks, so frames whose width is not a multiple of 256 would leave the last block of every row part
+    // empty (1920: 6 %, 640: 19 %): it gets FG frames side by side in one plane, Wp columns apart, and treats the group
+    // as one wide frame whose strips know their frame (sad_strip.inc).
+    int FG = 1, Wp = cols;
+    long blocksg = 0;
+    if (use_strip) strip_frame_groups(cols, n_pairs, false, &FG, &Wp, &blocksg);
+    // The on-the-fly form reads single-channel inputs itself: no prep pass (7-8 % of a step at D <= 32, 4 % at 64, and one
+    // launch less per call), with the same frame groups (tools/fg_stride.py, profiles/r02f_otf_direct_frame_groups.txt: 64 x
+    // 1080p at 7x7 / D = 30: 0.98 ms against 0.955 + 0.085).  Not for inputs the GPU reads over PCIe (the host API's zero-copy
+    // staging): the matcher reads every byte ~5 times.
+    // (64-thread blocks with windows from 13 columns up: two staging units per lane, the direct variant spills 8-39 VGPRs;
+    // 256-thread blocks with windows up to 13: the plane-reading variant stages the E words of L, which wins back a little more
+    // than the prep pass costs on large jobs -- 64 x 1080p at 9x9 / D = 64: 1.865 + 0.086 ms against 1.969)
+    bool direct = use_strip && use_otf && channels == 1 && !host_inputs && env().direct != 0 && cols + 32 < 65000 &&
+                  !(otf_ng == 1 && win >= 13 && env().direct < 0) &&
+                  !(otf_ng >= 4 && win <= 13 && (long)n_pairs * nvalid * cols > 4000000L && env().direct < 0) &&
+                  (int64_t)need_rows * (pitchL > pitchR ? pitchL : pitchR) < 0x7ff00000LL;
+    if (direct) {
+        strip_frame_groups(cols, n_pairs, true, &FG, &Wp, &blocksg);
+        sk = pick_strip_otf_kernel(win, otf_ng, true, &otf_lds);
+    }
+    if (use_strip && !direct && ((size_t)(PADL + (size_t)(FG - 1) * Wp + cols + PADR + 127) & ~(size_t)127) * (size_t)need_rows > 0x7ff00000u) {
+        FG = 1; Wp = cols;                                    // the strip matcher addresses the R plane with 32-bit offsets
+        if ((size_t)((PADL + cols + PADR + 127) & ~127) * (size_t)need_rows > 0x7ff00000u) use_strip = false;
+    }
+    const bool strip_zeroes = use_strip && rows_out - nvalid <= 64;
+    const int n_groups = (n_pairs + FG - 1) / FG;
+    const int vcols = (FG - 1) * Wp + cols;                    // columns of a group's plane that hold frames
+    const int pitch = (PADL + vcols + PADR + 127) & ~127;
+    const size_t plane_bytes = (size_t)pitch * (size_t)need_rows;
+    // scratch layout: [group][L plane | R plane], + slack: the strip matcher stages whole 256-column blocks
+    // and may read a few hundred bytes past the last row (values only reach columns >= cols-win, which are 0)
+    const size_t planes_need = 2 * plane_bytes * (size_t)n_groups + 4096;
+    sp.use_strip = use_strip; sp.use_otf = use_strip && use_otf; sp.direct = direct; sp.strip_zeroes = strip_zeroes;
+    sp.ng = strip_ng; sp.FG = FG; sp.Wp = Wp; sp.n_groups = n_groups; sp.vcols = vcols; sp.pitch = pitch;
+    sp.plane_bytes = plane_bytes; sp.planes_need = planes_need; sp.kernel = sk;
+    if (!use_strip) return sp;
+
+    const int bx = (vcols + strip::XBW - 1) / strip::XBW;
+    // rows per block: a block is 64*NG threads and two blocks fit a CU only up to NG = 8, so the grid is a few
+    // hundred large blocks and its quantisation matters.  Minimise rounds x steps-per-block over band heights
+    // that fill whole rounds of block slots (a round whose CUs hold a single block runs ~0.65 as long).
+    const int TY = (use_otf && strip_ng <= 4) ? otf_band_rows(bx, n_groups, nvalid, win, strip_ng, cus) : strip_band_rows(bx, n_groups, nvalid, win, strip_ng, cus);
+    int PR = 0, ROWW = 0;
+    if (!use_otf) strip_geometry(win, strip::NS + strip_ng, &PR, &ROWW);
+    sp.lds = use_otf ? (size_t)otf_lds : (size_t)(4 * ROWW + 3 * 64 * PR + 2 * 4 * 64 + 64) * 4;
+    sp.bx = bx; sp.TY = TY; sp.nby = (nvalid + TY - 1) / TY;
+    sp.nblocks = (long)sp.bx * sp.nby * n_groups;
+    const long chunk_units = (sp.nblocks + 7) / 8;            // per XCD
+    if (use_otf && env().tail != 0 && TY >= (env().tail > 0 ? 1 : 8)) {
+        // on-the-fly kernels: the last round of block slots of every XCD runs as half-height blocks: 64 x 1080p at 7x7 / D = 30
+        // -3.7 %, 32 x 4K -1.5 %, config 2 -1 % (SADBM_TAIL sweep: one round is the best size); jobs of fewer than three rounds
+        // gain nothing or lose 1-2 % to the extra warm-up rows, they keep whole blocks
+        const long slots_xcd = (long)(cus / 8 > 0 ? cus / 8 : 1) * (16 / strip_ng);
+        long t = env().tail > 0 ? env().tail : slots_xcd;
+        if (t > chunk_units / 2) t = chunk_units / 2;
+        if (env().tail < 0 && chunk_units < 3 * slots_xcd) t = 0;
+        sp.tail = (int)t;
+    }
+    return sp;
+}
+
 // The whole device pipeline for n_pairs frames (or one band).  Input rows available: rows_in; output
 // rows written: rows_out; output rows [0,nvalid) are computed, the rest zero-filled.
 int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_t *dR, int64_t pitchR,
@@ -581,57 +678,13 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
 
     const int need_rows = nvalid + win - 1;                   // <= rows_in (checked by callers)
 
-    // matcher choice: SADBM_KERNEL_STRIP / SADBM_KERNEL_QUAD force one; env SADBM_MATCHER=strip|quad overrides the default
-    bool use_strip = false;
-    int strip_ng = D <= 64 ? 4 : D <= 128 ? 8 : 16;          // disparity groups of 16 per block (multiple of 4)
-    strip_kernel_t sk = (win <= MAXWIN && cols < 65000) ? pick_strip_kernel(win, strip::NS + strip_ng) : nullptr;
-    // short searches: the on-the-fly form (blocks of 1, 2 or 4 groups of 16 disparities, strip_otf_kernels.hip)
-    int otf_lds = 0;
-    int otf_ng = D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : 8;
-    if (env().otf_ng > otf_ng) otf_ng = env().otf_ng;
-    strip_kernel_t sk_otf = (D <= 128 && win <= MAXWIN && cols < 65000 && env().otf != 0) ? pick_strip_otf_kernel(win, otf_ng, false, &otf_lds) : nullptr;
-    const bool use_otf = sk_otf != nullptr && (env().otf == 1 || otf_is_default(win, D, cols, nvalid, n_pairs));
-    if (use_otf) { sk = sk_otf; strip_ng = otf_ng; }
-    if (sk && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL | SADBM_KERNEL_QUAD))) {
-        use_strip = (flags & SADBM_KERNEL_STRIP) != 0 || use_otf || strip_is_default(win, D, cols, nvalid, n_pairs);
-        if (env().matcher && !(flags & SADBM_KERNEL_STRIP)) use_strip = env().matcher == 1;
-    }
-
-    // Scratch planes.  The quad / generic matchers get one padded plane pair per frame.  The strip matcher works on
-    // 256-column blocks, so frames whose width is not a multiple of 256 would leave the last block of every row part
-    // empty (1920: 6 %, 640: 19 %): it gets FG frames side by side in one plane, Wp columns apart, and treats the group
-    // as one wide frame whose strips know their frame (sad_strip.inc).
-    int FG = 1, Wp = cols;
-    long blocksg = 0;
-    if (use_strip) strip_frame_groups(cols, n_pairs, false, &FG, &Wp, &blocksg);
-    // The on-the-fly form reads single-channel inputs itself: no prep pass (7-8 % of a step at D <= 32, 4 % at 64, and one
-    // launch less per call), with the same frame groups (tools/fg_stride.py, profiles/r02f_otf_direct_frame_groups.txt: 64 x
-    // 1080p at 7x7 / D = 30: 0.98 ms against 0.955 + 0.085).  Not for inputs the GPU reads over PCIe (the host API's zero-copy
-    // staging): the matcher reads every byte ~5 times.
-    // (64-thread blocks with windows from 13 columns up: two staging units per lane, the direct variant spills 8-39 VGPRs;
-    // 256-thread blocks with windows up to 13: the plane-reading variant stages the E words of L, which wins back a little more
-    // than the prep pass costs on large jobs -- 64 x 1080p at 9x9 / D = 64: 1.865 + 0.086 ms against 1.969)
-    bool direct = use_strip && use_otf && channels == 1 && !ctx->host_inputs && env().direct != 0 && cols + 32 < 65000 &&
-                  !(otf_ng == 1 && win >= 13 && env().direct < 0) &&
-                  !(otf_ng >= 4 && win <= 13 && (long)n_pairs * nvalid * cols > 4000000L && env().direct < 0) &&
-                  (int64_t)need_rows * (pitchL > pitchR ? pitchL : pitchR) < 0x7ff00000LL;
-    if (direct) {
-        strip_frame_groups(cols, n_pairs, true, &FG, &Wp, &blocksg);
-        sk = pick_strip_otf_kernel(win, otf_ng, true, &otf_lds);
-    }
-    if (use_strip && !direct && ((size_t)(PADL + (size_t)(FG - 1) * Wp + cols + PADR + 127) & ~(size_t)127) * (size_t)need_rows > 0x7ff00000u) {
-        FG = 1; Wp = cols;                                    // the strip matcher addresses the R plane with 32-bit offsets
-        if ((size_t)((PADL + cols + PADR + 127) & ~127) * (size_t)need_rows > 0x7ff00000u) use_strip = false;
-    }
-    const bool strip_zeroes = use_strip && rows_out - nvalid <= 64;
+    // matcher choice, frame groups, direct reads, grid shape of the strip family: plan_strip (no HIP calls in it)
+    const StripPlan sp = plan_strip(ctx->cus, ctx->host_inputs, pitchL, pitchR, n_pairs, rows_out, nvalid, cols, channels, win, D, flags);
+    const bool use_strip = sp.use_strip, use_otf = sp.use_otf, direct = sp.direct, strip_zeroes = sp.strip_zeroes;
+    const int FG = sp.FG, Wp = sp.Wp, n_groups = sp.n_groups, pitch = sp.pitch;
+    const size_t plane_bytes = sp.plane_bytes, planes_need = sp.planes_need;
+    const strip_kernel_t sk = sp.kernel;
     if (nvalid < rows_out && !strip_zeroes) { int zrc = zero_rows(); if (zrc) return zrc; }
-    const int n_groups = (n_pairs + FG - 1) / FG;
-    const int vcols = (FG - 1) * Wp + cols;                    // columns of a group's plane that hold frames
-    const int pitch = (PADL + vcols + PADR + 127) & ~127;
-    const size_t plane_bytes = (size_t)pitch * (size_t)need_rows;
-    // scratch layout: [group][L plane | R plane], + slack: the strip matcher stages whole 256-column blocks
-    // and may read a few hundred bytes past the last row (values only reach columns >= cols-win, which are 0)
-    const size_t planes_need = 2 * plane_bytes * (size_t)n_groups + 4096;
     if (ctx->planes_fixed && planes_need > ctx->planes_cap) return SADBM_E_LIMIT;     // static scratch: never grown (one documented limit, direct or not)
     int rc = (ctx->planes_fixed || direct) ? SADBM_OK : grow(&ctx->planes, &ctx->planes_cap, planes_need);
     if (rc) return rc;
@@ -666,48 +719,30 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
 
     if (use_strip) {
         strip::SParams q;
-        q.NG = strip_ng;
+        q.NG = sp.ng;
         q.Lrow0 = pL; q.pair_stride = (int64_t)(2 * plane_bytes); q.lr_delta = (uint32_t)plane_bytes;
         q.pitch = pitch; q.W = cols; q.nvalid = nvalid; q.win = win; q.D = D;
         q.out = dOut; q.out_pitch = out_pitch; q.out_stride = pair_stride_out; q.flags = flags; q.dword_store = p.dword_store;
         q.dL = dL; q.dR = dR; q.in_stride = pair_stride_in; q.pitchL = (int)pitchL; q.pitchR = (int)pitchR;
         q.extL = direct ? (int)((int64_t)(need_rows - 1) * pitchL + cols) : 0;
         q.extR = direct ? (int)((int64_t)(need_rows - 1) * pitchR + cols) : 0;
-        const int bx = (vcols + strip::XBW - 1) / strip::XBW;
-        // rows per block: a block is 64*NG threads and two blocks fit a CU only up to NG = 8, so the grid is a few
-        // hundred large blocks and its quantisation matters.  Minimise rounds x steps-per-block over band heights
-        // that fill whole rounds of block slots (a round whose CUs hold a single block runs ~0.65 as long).
-        int TY = (use_otf && q.NG <= 4) ? otf_band_rows(bx, n_groups, nvalid, win, q.NG, ctx->cus) : strip_band_rows(bx, n_groups, nvalid, win, q.NG, ctx->cus);
+        const int TY = sp.TY;
+        const size_t lds = sp.lds;
         q.TY = TY;
-        const int NSL = strip::NS + q.NG;
-        int PR = 0, ROWW = 0;
-        if (!use_otf) strip_geometry(win, NSL, &PR, &ROWW);
-        const size_t lds = use_otf ? (size_t)otf_lds : (size_t)(4 * ROWW + 3 * 64 * PR + 2 * 4 * 64 + 64) * 4;
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        q.nbx = bx; q.nby = (nvalid + TY - 1) / TY; q.ngroups = n_groups;
+        q.nbx = sp.bx; q.nby = sp.nby; q.ngroups = n_groups;
         q.FG = FG; q.Wp = Wp; q.npairs = n_pairs;
         q.rows_out = strip_zeroes ? rows_out : nvalid;
-        const long nblocks = (long)q.nbx * q.nby * q.ngroups;
-        if (nblocks > 0x3ffffff0L) return SADBM_E_SIZE;
-        q.tail = 0;
-        long chunk_units = (nblocks + 7) / 8;                  // per XCD
-        if (use_otf && env().tail != 0 && TY >= (env().tail > 0 ? 1 : 8)) {
-            // on-the-fly kernels: the last round of block slots of every XCD runs as half-height blocks: 64 x 1080p at 7x7 / D = 30
-            // -3.7 %, 32 x 4K -1.5 %, config 2 -1 % (SADBM_TAIL sweep: one round is the best size); jobs of fewer than three rounds
-            // gain nothing or lose 1-2 % to the extra warm-up rows, they keep whole blocks
-            const long slots_xcd = (long)(ctx->cus / 8 > 0 ? ctx->cus / 8 : 1) * (16 / q.NG);
-            long t = env().tail > 0 ? env().tail : slots_xcd;
-            if (t > chunk_units / 2) t = chunk_units / 2;
-            if (env().tail < 0 && chunk_units < 3 * slots_xcd) t = 0;
-            q.tail = (int)t;
-        }
+        if (sp.nblocks > 0x3ffffff0L) return SADBM_E_SIZE;
+        q.tail = sp.tail;
+        const long chunk_units = (sp.nblocks + 7) / 8;         // per XCD
         dim3 g((unsigned)(8 * (chunk_units + q.tail)));         // 1-D, XCD-aware order decoded in the kernel
         if (env().trace)
             fprintf(stderr, "sadbm: strip%s win %d D %d NG %d direct %d  %dx%d x%d  FG %d Wp %d  bx %d nby %d groups %d TY %d  tail %d  lds %zu\n", use_otf ? "_otf" : "",
                     win, D, q.NG, (int)direct, cols, nvalid, n_pairs, FG, Wp, q.nbx, q.nby, q.ngroups, TY, q.tail, lds);
         hipLaunchKernelGGL(sk, g, dim3(64 * q.NG), lds, st, q);
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), use_otf ? "sad_strip_otf_kernel<%d>" : "sad_strip_kernel<%d>", win);
-        if (use_otf) snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_strip_otf_kernel<%d,%d>%s", win, otf_ng, direct ? "+direct" : "");
+        if (use_otf) snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_strip_otf_kernel<%d,%d>%s", win, sp.ng, direct ? "+direct" : "");
         HIPCHK(hipGetLastError());
         if (prof) { HIPCHK(hipEventRecord(ev[2], st)); ctx->ev_n++; }
         return SADBM_OK;
@@ -867,6 +902,37 @@ int sadbm_ctx_taps(sadbm_ctx *ctx, double **taps, int count)
 }
 
 const char *sadbm_last_kernel_name(const sadbm_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
+
+int sadbm_plan_describe(int rows, int cols, int channels, int n_pairs, int win, int max_disp, uint32_t flags, int cus, char *text, int text_len)
+{
+    if (!text || text_len <= 0) return SADBM_E_NULL;
+    int rc = check_params(rows, cols, channels, win, max_disp, flags);
+    if (rc) return rc;
+    if (n_pairs < 1) return SADBM_E_SIZE;
+    if (cus <= 0) cus = 256;
+    int nvalid = rows - win;
+    if (nvalid < 0 || cols - win <= 0) nvalid = 0;
+    if (nvalid == 0 || rows == 0 || cols == 0) { snprintf(text, (size_t)text_len, "matcher=none"); return SADBM_OK; }
+    const StripPlan sp = plan_strip(cus, false, (int64_t)cols * channels, (int64_t)cols * channels, n_pairs, rows, nvalid, cols, channels, win,
+                                    max_disp, flags);
+    if (sp.use_strip) {
+        char name[64];
+        if (sp.use_otf) snprintf(name, sizeof(name), "sad_strip_otf_kernel<%d,%d>%s", win, sp.ng, sp.direct ? "+direct" : "");
+        else snprintf(name, sizeof(name), "sad_strip_kernel<%d>", win);
+        snprintf(text, (size_t)text_len, "matcher=%s kernel=%s threads=%d FG=%d Wp=%d groups=%d bx=%d TY=%d nby=%d blocks=%ld tail=%d lds=%zu scratch=%zu prep=%d",
+                 sp.use_otf ? "strip_otf" : "strip", name, 64 * sp.ng, sp.FG, sp.Wp, sp.n_groups, sp.bx, sp.TY, sp.nby, sp.nblocks, sp.tail, sp.lds,
+                 sp.direct ? (size_t)0 : sp.planes_need, sp.direct ? 0 : 1);
+    } else if (win > MAXWIN || (flags & SADBM_FORCE_GENERIC)) {
+        snprintf(text, (size_t)text_len, "matcher=generic kernel=sad_generic_kernel scratch=%zu prep=1", sp.planes_need);
+    } else if (flags & SADBM_KERNEL_GLOBAL) {
+        snprintf(text, (size_t)text_len, "matcher=quad kernel=sad_quad_kernel<%d> scratch=%zu prep=1", win, sp.planes_need);
+    } else {
+        int KC = max_disp <= 64 ? 8 : 16;
+        if (env().kc) KC = env().kc;
+        snprintf(text, (size_t)text_len, "matcher=quad kernel=sad_quad_lds_kernel<%d,%d> scratch=%zu prep=1", win, KC, sp.planes_need);
+    }
+    return SADBM_OK;
+}
 
 int sadbm_ctx_device(const sadbm_ctx *ctx) { return ctx ? ctx->device : -1; }
 

@@ -104,6 +104,8 @@ def load_library():
     L.sadbm_compute_multi_batch.argtypes = [vp, ctypes.POINTER(_Image), ctypes.POINTER(_Image), i32, i32, i32, u32, ctypes.POINTER(_Plane)]
     L.sadbm_band_plan.argtypes = [i32, i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.sadbm_reload_env.restype = None
+    L.sadbm_plan_describe.argtypes = [i32, i32, i32, i32, i32, i32, u32, i32, ctypes.c_char_p, i32]
+    L.sadbm_plan_describe.restype = i32
     L.sadbm_thread_release.restype = None
     for name in ("sadbm_compute_device_static", "sadbm_multi_create", "sadbm_compute_multi", "sadbm_multi_device_map",
                  "sadbm_compute_multi_batch", "sadbm_band_plan"):
@@ -188,6 +190,18 @@ def _ctx_for(device, stream=None):
     else:
         table.move_to_end(key)
     return c
+
+
+def plan(rows, cols, channels=1, n_pairs=1, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags=0, cus=0):
+    """sadbm_plan_describe as a dict: what a call on n_pairs whole device-resident frames would launch (needs no GPU)."""
+    buf = ctypes.create_string_buffer(512)
+    _check(load_library().sadbm_plan_describe(int(rows), int(cols), int(channels), int(n_pairs), int(winSize), int(DSR), int(flags),
+                                              int(cus), buf, len(buf)))
+    out = {}
+    for kv in buf.value.decode().split():
+        k, v = kv.split("=", 1)
+        out[k] = int(v) if v.lstrip("-").isdigit() else v
+    return out
 
 
 def reload_env():

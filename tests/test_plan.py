@@ -1,0 +1,69 @@
+"""CPU tests of the launch policy (sadbm_plan_describe: what run_pipeline decides before it touches the GPU): the kernels the
+BASELINE configurations get, and the invariants of frame groups, bands and grids over a few thousand parameter sets."""
+import numpy as np
+import pytest
+
+import opencv_amd as oa
+
+
+def test_baseline_configurations_get_the_documented_kernels():
+    p = oa.plan(288, 384, 3, 1, 7, 30)                      # the reference's own call: BGR pair, winSize 7, DSR 30 (SAD.cpp:9,11,65-66)
+    assert p["kernel"] == "sad_strip_otf_kernel<7,2>" and p["prep"] == 1 and p["threads"] == 128
+    p = oa.plan(288, 384, 1, 256, 7, 30)                    # config 1 as a batch of grey frames: read in place, two frames per group
+    assert p["kernel"] == "sad_strip_otf_kernel<7,2>+direct" and p["scratch"] == 0 and p["FG"] == 2 and p["bx"] == 3
+    p = oa.plan(1080, 1920, 1, 64, 9, 64)                   # config 2
+    assert p["kernel"] == "sad_strip_otf_kernel<9,4>" and p["FG"] == 2 and p["bx"] == 15 and p["tail"] > 0
+    p = oa.plan(2160, 3840, 1, 32, 15, 128)                 # config 3
+    assert p["kernel"] == "sad_strip_kernel<15>" and p["threads"] == 512 and p["FG"] == 1 and p["bx"] == 15
+    p = oa.plan(4320, 7680, 1, 4, 21, 256)                  # config 4
+    assert p["kernel"] == "sad_strip_kernel<21>" and p["threads"] == 1024 and p["bx"] == 30
+    p = oa.plan(375, 1242, 1, 512, 7, 128)                  # config 5: 8 frames side by side fill 39 blocks of 256 columns
+    assert p["kernel"] == "sad_strip_kernel<7>" and p["FG"] == 8 and p["Wp"] == 1248 and p["bx"] == 39
+    assert oa.plan(1080, 1920, 1, 1, 3, 30)["matcher"] == "quad"
+    assert oa.plan(100, 100, 1, 1, 31, 30)["matcher"] == "generic"
+    assert oa.plan(7, 100, 1, 1, 7, 30)["matcher"] == "none"        # rows <= winSize: all-zero result, nothing to launch
+    assert oa.plan(1080, 1920, 1, 1, 7, 30, oa.KERNEL_QUAD)["kernel"] == "sad_quad_lds_kernel<7,8>"
+    assert oa.plan(1080, 1920, 1, 32, 7, 100)["kernel"] == "sad_strip_otf_kernel<7,8>"     # D % 16 != 0 up to 128: poisoned sums
+    assert oa.plan(1080, 1920, 1, 32, 7, 112)["kernel"] == "sad_strip_kernel<7>"
+
+
+def test_plan_rejects_what_the_calls_reject():
+    for args, code in (((10, 10, 2, 1, 7, 30), -2), ((10, 10, 1, 1, 0, 30), -4), ((10, 10, 1, 1, 7, 0), -4), ((10, 10, 1, 1, 7, 257), -4),
+                       ((10, 10, 1, 0, 7, 30), -3)):
+        with pytest.raises(oa.SadbmError) as e:
+            oa.plan(*args)
+        assert e.value.code == code, args
+
+
+def test_strip_plans_cover_the_job():
+    rng = np.random.default_rng(4)
+    n_strip = 0
+    for _ in range(3000):
+        win = int(rng.integers(4, 26))
+        D = int(rng.choice([1, 8, 16, 17, 30, 32, 33, 64, 65, 100, 128, 129, 200, 256]))
+        rows = int(rng.choice([win + 1, int(rng.integers(win + 1, 400)), 480, 1080, 2160, 4320]))
+        cols = int(rng.choice([win + 1, int(rng.integers(win + 1, 700)), 384, 640, 1242, 1920, 2048, 3840, 7680]))
+        n = int(rng.choice([1, 1, 2, 3, 7, 32, 64, 256, 1000]))
+        ch = int(rng.choice([1, 1, 3, 4]))
+        p = oa.plan(rows, cols, ch, n, win, D)
+        if not p["matcher"].startswith("strip"):
+            continue
+        n_strip += 1
+        nvalid = rows - win
+        FG, Wp, groups, bx, TY, nby = p["FG"], p["Wp"], p["groups"], p["bx"], p["TY"], p["nby"]
+        what = (rows, cols, ch, n, win, D, p)
+        assert FG >= 1 and groups * FG >= n > (groups - 1) * FG, what                   # every frame in exactly one group
+        assert Wp >= cols and (FG == 1 or Wp % 16 == 0), what                            # strips never straddle two frames
+        assert bx * 256 >= (FG - 1) * Wp + cols > (bx - 1) * 256, what                   # column blocks cover the group, none is empty
+        assert (FG - 1) * Wp + cols < 65536, what                                        # 16-bit column fields
+        assert TY >= 1 and nby * TY >= nvalid > (nby - 1) * TY, what                     # bands cover the computed rows, none is empty
+        assert p["blocks"] == bx * nby * groups, what
+        assert 0 <= p["tail"] <= (p["blocks"] + 7) // 8 // 2, what
+        assert p["lds"] <= 160 * 1024 and p["threads"] in (64, 128, 256, 512, 1024), what
+        assert 16 * (p["threads"] // 64) >= D, what                                      # the block's disparity slots cover the search
+        if p["matcher"] == "strip_otf":
+            assert D <= 128 and p["lds"] <= 16 * 1024, what
+            assert (p["prep"] == 0) == p["kernel"].endswith("+direct") and (p["prep"] == 1 or (ch == 1 and p["scratch"] == 0)), what
+        else:
+            assert p["prep"] == 1 and p["scratch"] > 2 * (rows - 1) * cols * groups, what
+    assert n_strip > 2000

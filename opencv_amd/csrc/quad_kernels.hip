@@ -553,6 +553,6 @@ quad_kernel_t pick_quad_lds_kernel_t(int win, int kc, Seq<I...>)
 }  // namespace
 
 quad_kernel_t pick_quad_kernel(int win) { return pick_quad_kernel_t(win, MakeSeq<MAXWIN>::type()); }
-quad_kernel_t pick_quad_lds_kernel(int win, int kc) { return pick_quad_lds_kernel_t(win, kc, MakeSeq<MAXWIN>::type()); }
+quad_kernel_t pick_quad_lds_kernel(int win, int kc) { return pick_quad_lds_kernel_t(win, kc, MakeSeq<QUAD_MAXWIN>::type()); }
 
 }  // namespace sadbm_detail

@@ -16,7 +16,7 @@
 //                              disparities; sad_strip_kernel<WIN,NSLM> (sad_strip.inc: the same work split with every operand
 //                              staged as a ready-made dword in LDS) above; sad_quad_lds_kernel<WIN,KC> (quad_kernels.hip) for
 //                              windows below 4 columns and a few 4-wide cases; sad_quad_kernel<WIN> = the same arithmetic
-//                              with operands through L1 (A/B flag); sad_generic_kernel for win > MAXWIN.
+//                              with operands through L1 (A/B flag); sad_generic_kernel for win > QUAD_MAXWIN (49).
 //
 // The quad matcher lives in quad_kernels.hip, the strip matchers in sad_strip.inc / strip_kernels.hip /
 // strip_otf_kernels.hip (separate translation units so they compile in parallel); sadbm_internal.hpp holds what they share.
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) zero_rows_kernel(uint8_t *out, int64_t ou
     for (int b = 0; b < 4 && x + b < cols; ++b) o[b] = 0;
 }
 
-// Brute-force matcher for any window (win > MAXWIN or SADBM_FORCE_GENERIC): one thread per output
+// Brute-force matcher for any window (win > QUAD_MAXWIN or SADBM_FORCE_GENERIC): one thread per output
 // pixel, window SAD with v_sad_u8 on bytes from the padded planes.  Correctness path, not tuned.
 __global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
 {
@@ -748,7 +748,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         return SADBM_OK;
     }
 
-    if (win > MAXWIN || (flags & SADBM_FORCE_GENERIC)) {
+    if (win > QUAD_MAXWIN || (win > MAXWIN && (flags & SADBM_KERNEL_GLOBAL)) || (flags & SADBM_FORCE_GENERIC)) {
         dim3 g((cols + 255) / 256, nvalid, n_pairs);
         hipLaunchKernelGGL(sad_generic_kernel, g, dim3(256), 0, st, p);
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_generic_kernel");
@@ -922,7 +922,7 @@ int sadbm_plan_describe(int rows, int cols, int channels, int n_pairs, int win, 
         snprintf(text, (size_t)text_len, "matcher=%s kernel=%s threads=%d FG=%d Wp=%d groups=%d bx=%d TY=%d nby=%d blocks=%ld tail=%d lds=%zu scratch=%zu prep=%d",
                  sp.use_otf ? "strip_otf" : "strip", name, 64 * sp.ng, sp.FG, sp.Wp, sp.n_groups, sp.bx, sp.TY, sp.nby, sp.nblocks, sp.tail, sp.lds,
                  sp.direct ? (size_t)0 : sp.planes_need, sp.direct ? 0 : 1);
-    } else if (win > MAXWIN || (flags & SADBM_FORCE_GENERIC)) {
+    } else if (win > QUAD_MAXWIN || (win > MAXWIN && (flags & SADBM_KERNEL_GLOBAL)) || (flags & SADBM_FORCE_GENERIC)) {
         snprintf(text, (size_t)text_len, "matcher=generic kernel=sad_generic_kernel scratch=%zu prep=1", sp.planes_need);
     } else if (flags & SADBM_KERNEL_GLOBAL) {
         snprintf(text, (size_t)text_len, "matcher=quad kernel=sad_quad_kernel<%d> scratch=%zu prep=1", win, sp.planes_need);

@@ -14,7 +14,9 @@ namespace sadbm_detail {
 
 constexpr int PADL = 320;     // >= 256 + 3 + slack; keeps every R read at x0-k-3 >= -PADL addressable
 constexpr int PADR = 64;      // >= 4*NW + 8 for the widest window
-constexpr int MAXWIN = 25;    // widest window with a dedicated instantiation
+constexpr int MAXWIN = 25;    // widest window of the strip matchers (and of the L1-operand quad variant)
+constexpr int QUAD_MAXWIN = 49; // widest window of sad_quad_lds_kernel (4 * ((win + 6) / 4) <= PADR - 8: a quad's words stay inside the right padding);
+                              // beyond it the brute-force kernel takes over -- 300 times slower, so the quad matcher reaches as far as it can
 constexpr uint32_t KEY_MAX = 0xFFFFFFFFu;
 
 struct Params {
@@ -63,7 +65,7 @@ typedef void (*strip_kernel_t)(strip::SParams);
 
 // quad_kernels.hip
 quad_kernel_t pick_quad_kernel(int win);                 // sad_quad_kernel<win>, 1 <= win <= MAXWIN
-quad_kernel_t pick_quad_lds_kernel(int win, int kc);     // sad_quad_lds_kernel<win, kc>, kc in {8, 16}
+quad_kernel_t pick_quad_lds_kernel(int win, int kc);     // sad_quad_lds_kernel<win, kc>, kc in {8, 16}, 1 <= win <= QUAD_MAXWIN
 // strip_kernels.hip: nslm = NS + (4, 8 or 16 disparity groups); nullptr where the window has no strip instantiation
 strip_kernel_t pick_strip_kernel(int win, int nslm);
 // strip_otf_kernels.hip: the on-the-fly form of the strip matcher, ng = 1, 2 or 4 disparity groups per block (64 ng threads); its dynamic LDS size

@@ -267,3 +267,21 @@ def test_config5_kitti_batch_against_oracle():
     out = oa.compute_batch_device(dev(np.stack([p[0] for p in pairs])), dev(np.stack([p[1] for p in pairs])), win, D).cpu().numpy()
     for n, (L, R) in enumerate(pairs):
         assert np.array_equal(out[n], oracle.box(L, R, win, D)), n
+
+
+@pytest.mark.parametrize("win", [26, 27, 29, 31, 32, 33, 40, 48, 49, 50])
+def test_windows_beyond_the_strip_matchers(win):
+    """Windows wider than 25 columns have no strip instantiation: the quad matcher serves them up to 49 (32-bit costs), the
+    brute-force kernel beyond -- frames around the block sizes, batches, binary dots, BGR, D not a multiple of 8."""
+    import torch
+    from helpers import kname
+    for (H, W, n, D, binary) in ((win + 5, 300, 1, 30, False), (win + 9, 517, 3, 64, True), (win + 2, win + 70, 2, 200, False), (70, 260, 1, 13, False)):
+        Ls, Rs = zip(*[noise_pair(win * 31 + D + i, H, W, shift=min(7 + i, D - 1), binary=binary) for i in range(n)])
+        ctx = oa.Context(0)
+        out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, oa.RAW_LOC, ctx=ctx).cpu().numpy()
+        assert kname(ctx) == ("sad_quad_lds_kernel<%d,%d>" % (win, 8 if D <= 64 else 16) if win <= 49 else "sad_generic_kernel")
+        for i in range(n):
+            exp = oracle.box(Ls[i], Rs[i], win, D, oracle.RAW_LOC)
+            assert np.array_equal(out[i], exp), (win, H, W, D, i, np.argwhere(out[i] != exp)[:4])
+    L, R = noise_pair(win, win + 20, 200, shift=4, ch=3)
+    assert np.array_equal(oa.get_disparity_host(L, R, win, 30), oracle.literal(np.ascontiguousarray(L[:, :, 0]), np.ascontiguousarray(R[:, :, 0]), win, 30))

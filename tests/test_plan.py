@@ -20,7 +20,8 @@ def test_baseline_configurations_get_the_documented_kernels():
     p = oa.plan(375, 1242, 1, 512, 7, 128)                  # config 5: 8 frames side by side fill 39 blocks of 256 columns
     assert p["kernel"] == "sad_strip_kernel<7>" and p["FG"] == 8 and p["Wp"] == 1248 and p["bx"] == 39
     assert oa.plan(1080, 1920, 1, 1, 3, 30)["matcher"] == "quad"
-    assert oa.plan(100, 100, 1, 1, 31, 30)["matcher"] == "generic"
+    assert oa.plan(100, 100, 1, 1, 31, 30)["kernel"] == "sad_quad_lds_kernel<31,8>"       # 26 ... 49: the quad matcher (no strip instantiation)
+    assert oa.plan(100, 100, 1, 1, 50, 30)["matcher"] == "generic"
     assert oa.plan(7, 100, 1, 1, 7, 30)["matcher"] == "none"        # rows <= winSize: all-zero result, nothing to launch
     assert oa.plan(1080, 1920, 1, 1, 7, 30, oa.KERNEL_QUAD)["kernel"] == "sad_quad_lds_kernel<7,8>"
     assert oa.plan(1080, 1920, 1, 32, 7, 100)["kernel"] == "sad_strip_otf_kernel<7,8>"     # D % 16 != 0 up to 128: poisoned sums

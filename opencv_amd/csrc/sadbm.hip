@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) zero_rows_kernel(uint8_t *out, int64_t ou
 }
 
 // Brute-force matcher for any window (win > QUAD_MAXWIN or SADBM_FORCE_GENERIC): one thread per output
-// pixel, window SAD with v_sad_u8 on bytes from the padded planes.  Correctness path, not tuned.
+// pixel, window SAD with v_sad_u8 on words from the padded planes.  Correctness path, not tuned.
 __global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -177,12 +177,18 @@ __global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
     if (x >= ocols) { out[x] = 0; return; }
     const int kmax = min(x, p.D - 1);
     uint32_t best = KEY_MAX;
+    // four bytes per v_sad_u8 (byte-granular dword loads; the planes are padded, so the word that holds the window's last
+    // 1-3 bytes is readable -- its other bytes are masked away in both operands)
+    typedef uint32_t u32u __attribute__((aligned(1)));
+    const int nw = p.win >> 2, rem = p.win & 3;
+    const uint32_t tail_mask = rem ? (0xFFFFFFFFu >> (8 * (4 - rem))) : 0u;
     for (int k = 0; k <= kmax; ++k) {
         uint32_t cost = 0;
         for (int dy = 0; dy < p.win; ++dy) {
             const uint8_t *pl = L + (int64_t)(y + dy) * p.pitch + x;
             const uint8_t *pr = R + (int64_t)(y + dy) * p.pitch + x - k;
-            for (int dx = 0; dx < p.win; ++dx) cost = __builtin_amdgcn_sad_u8(pl[dx], pr[dx], cost);
+            for (int w = 0; w < nw; ++w) cost = __builtin_amdgcn_sad_u8(*(const u32u *)(pl + 4 * w), *(const u32u *)(pr + 4 * w), cost);
+            if (rem) cost = __builtin_amdgcn_sad_u8(*(const u32u *)(pl + 4 * nw) & tail_mask, *(const u32u *)(pr + 4 * nw) & tail_mask, cost);
         }
         best = min(best, (cost << 8) | (uint32_t)k);          // cost < 2^24 for win <= 255
     }

@@ -197,6 +197,83 @@ __global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
     out[x] = (p.flags & SADBM_RAW_LOC) ? (uint8_t)loc : (uint8_t)((loc * 16u) & 0xFFu);
 }
 
+// Windows beyond the quad matcher (50..255 columns): O(win) lane-ops per evaluation instead of the brute force's O(win^2 / 4).
+// A block is 256 adjacent columns x WIDE_TY output rows.  Thread t keeps, for eight disparities at a time, the vertical
+// running sums of |L - R| over the window's rows in column XB + t (one row enters and one leaves per step, SAD.cpp:13-22's
+// sum split into columns); each output row the block exchanges them through LDS (double-buffered: one barrier per row) and
+// thread t < NX = 257 - win adds the win columns t .. t+win-1.  The running first-minimum key of every (row, column) lives in
+// a thread-private LDS cell between the passes over the disparity chunks.  cost < 255^3 < 2^24: key = cost << 8 | k.
+constexpr int WIDE_TY = 32;
+__global__ void __launch_bounds__(256) sad_wide_kernel(Params p)
+{
+    __shared__ uint4 cs_lo[2][256], cs_hi[2][256];
+    __shared__ uint32_t best_s[WIDE_TY][256];
+    typedef uint32_t u32u __attribute__((aligned(1)));
+    const int tid = threadIdx.x, NX = 257 - p.win;
+    const int xc = blockIdx.x * NX + tid;
+    const int yb = blockIdx.y * WIDE_TY, ny = min(WIDE_TY, p.nvalid - yb);
+    const uint8_t *L = p.L + (int64_t)blockIdx.z * p.plane_stride + (int64_t)yb * p.pitch + xc;
+    const uint8_t *R = p.R + (int64_t)blockIdx.z * p.plane_stride + (int64_t)yb * p.pitch + xc;
+    const int ocols = p.W - p.win;
+    const bool col_ok = xc < p.W;                      // columns beyond the frame feed no output column (x + win - 1 < W - 1)
+    const bool out_ok = tid < NX && xc < ocols;
+    for (int ry = 0; ry < ny; ++ry) best_s[ry][tid] = KEY_MAX;
+    int it = 0;
+    for (int kc = 0; kc < p.D; kc += 8) {
+        uint32_t cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < ny + p.win - 1; ++r) {
+            if (col_ok) {
+                // disparity kc + j pairs L[xc] with R[xc - kc - j]: eight bytes that end at R[xc - kc] (left padding: zeros)
+                const uint8_t *pr = R + (int64_t)r * p.pitch - kc - 7;
+                const uint32_t lb = L[(int64_t)r * p.pitch], r0 = *(const u32u *)pr, r1 = *(const u32u *)(pr + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cs[j] = __builtin_amdgcn_sad_u8(lb, (r1 >> (8 * (3 - j))) & 0xFFu, cs[j]);
+                    cs[4 + j] = __builtin_amdgcn_sad_u8(lb, (r0 >> (8 * (3 - j))) & 0xFFu, cs[4 + j]);
+                }
+                if (r >= p.win) {
+                    const uint8_t *qr = pr - (int64_t)p.win * p.pitch;
+                    const uint32_t mb = L[(int64_t)(r - p.win) * p.pitch], q0 = *(const u32u *)qr, q1 = *(const u32u *)(qr + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        cs[j] -= __builtin_amdgcn_sad_u8(mb, (q1 >> (8 * (3 - j))) & 0xFFu, 0u);
+                        cs[4 + j] -= __builtin_amdgcn_sad_u8(mb, (q0 >> (8 * (3 - j))) & 0xFFu, 0u);
+                    }
+                }
+            }
+            if (r >= p.win - 1) {                      // uniform over the block
+                cs_lo[it][tid] = make_uint4(cs[0], cs[1], cs[2], cs[3]);
+                cs_hi[it][tid] = make_uint4(cs[4], cs[5], cs[6], cs[7]);
+                __syncthreads();
+                if (out_ok) {
+                    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int i = 0; i < p.win; ++i) {
+                        const uint4 u = cs_lo[it][tid + i], v = cs_hi[it][tid + i];      // tid + i <= NX - 1 + win - 1 = 255
+                        a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w;
+                        a[4] += v.x; a[5] += v.y; a[6] += v.z; a[7] += v.w;
+                    }
+                    uint32_t b = best_s[r - (p.win - 1)][tid];
+                    const int kmax = min(xc, p.D - 1);          // slots k > column keep cost 0 (SAD.cpp:40 skips them): added below
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (kc + j <= kmax) b = min(b, (a[j] << 8) | (uint32_t)(kc + j));
+                    best_s[r - (p.win - 1)][tid] = b;
+                }
+                it ^= 1;
+            }
+        }
+    }
+    if (tid < NX && xc < p.W) {
+        uint8_t *out = p.out + (int64_t)blockIdx.z * p.out_stride + (int64_t)yb * p.out_pitch + xc;
+        for (int ry = 0; ry < ny; ++ry) {
+            uint32_t b = best_s[ry][tid];
+            if (xc + 1 < p.D) b = min(b, (uint32_t)(xc + 1));
+            const uint32_t loc = b & 0xFFu;
+            out[(int64_t)ry * p.out_pitch] = xc >= ocols ? (uint8_t)0 : (p.flags & SADBM_RAW_LOC) ? (uint8_t)loc : (uint8_t)((loc * 16u) & 0xFFu);
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -754,7 +831,13 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         return SADBM_OK;
     }
 
-    if (win > QUAD_MAXWIN || (win > MAXWIN && (flags & SADBM_KERNEL_GLOBAL)) || (flags & SADBM_FORCE_GENERIC)) {
+    if (win > QUAD_MAXWIN && !(flags & SADBM_FORCE_GENERIC)) {
+        const int NX = 257 - win;                                // output columns per block (win <= 255)
+        dim3 g((cols + NX - 1) / NX, (nvalid + WIDE_TY - 1) / WIDE_TY, n_pairs);
+        if (g.y > 65535u || g.z > 65535u) return SADBM_E_SIZE;
+        hipLaunchKernelGGL(sad_wide_kernel, g, dim3(256), 0, st, p);
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_wide_kernel");
+    } else if ((win > MAXWIN && (flags & SADBM_KERNEL_GLOBAL)) || (flags & SADBM_FORCE_GENERIC)) {
         dim3 g((cols + 255) / 256, nvalid, n_pairs);
         hipLaunchKernelGGL(sad_generic_kernel, g, dim3(256), 0, st, p);
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_generic_kernel");
@@ -928,7 +1011,9 @@ int sadbm_plan_describe(int rows, int cols, int channels, int n_pairs, int win, 
         snprintf(text, (size_t)text_len, "matcher=%s kernel=%s threads=%d FG=%d Wp=%d groups=%d bx=%d TY=%d nby=%d blocks=%ld tail=%d lds=%zu scratch=%zu prep=%d",
                  sp.use_otf ? "strip_otf" : "strip", name, 64 * sp.ng, sp.FG, sp.Wp, sp.n_groups, sp.bx, sp.TY, sp.nby, sp.nblocks, sp.tail, sp.lds,
                  sp.direct ? (size_t)0 : sp.planes_need, sp.direct ? 0 : 1);
-    } else if (win > QUAD_MAXWIN || (win > MAXWIN && (flags & SADBM_KERNEL_GLOBAL)) || (flags & SADBM_FORCE_GENERIC)) {
+    } else if (win > QUAD_MAXWIN && !(flags & SADBM_FORCE_GENERIC)) {
+        snprintf(text, (size_t)text_len, "matcher=wide kernel=sad_wide_kernel scratch=%zu prep=1", sp.planes_need);
+    } else if ((win > MAXWIN && (flags & SADBM_KERNEL_GLOBAL)) || (flags & SADBM_FORCE_GENERIC)) {
         snprintf(text, (size_t)text_len, "matcher=generic kernel=sad_generic_kernel scratch=%zu prep=1", sp.planes_need);
     } else if (flags & SADBM_KERNEL_GLOBAL) {
         snprintf(text, (size_t)text_len, "matcher=quad kernel=sad_quad_kernel<%d> scratch=%zu prep=1", win, sp.planes_need);

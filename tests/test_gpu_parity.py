@@ -272,16 +272,37 @@ def test_config5_kitti_batch_against_oracle():
 @pytest.mark.parametrize("win", [26, 27, 29, 31, 32, 33, 40, 48, 49, 50])
 def test_windows_beyond_the_strip_matchers(win):
     """Windows wider than 25 columns have no strip instantiation: the quad matcher serves them up to 49 (32-bit costs), the
-    brute-force kernel beyond -- frames around the block sizes, batches, binary dots, BGR, D not a multiple of 8."""
+    column-sum matcher (sad_wide_kernel) beyond -- frames around the block sizes, batches, binary dots, BGR, D not a multiple of 8."""
     import torch
     from helpers import kname
     for (H, W, n, D, binary) in ((win + 5, 300, 1, 30, False), (win + 9, 517, 3, 64, True), (win + 2, win + 70, 2, 200, False), (70, 260, 1, 13, False)):
         Ls, Rs = zip(*[noise_pair(win * 31 + D + i, H, W, shift=min(7 + i, D - 1), binary=binary) for i in range(n)])
         ctx = oa.Context(0)
         out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, oa.RAW_LOC, ctx=ctx).cpu().numpy()
-        assert kname(ctx) == ("sad_quad_lds_kernel<%d,%d>" % (win, 8 if D <= 64 else 16) if win <= 49 else "sad_generic_kernel")
+        assert kname(ctx) == ("sad_quad_lds_kernel<%d,%d>" % (win, 8 if D <= 64 else 16) if win <= 49 else "sad_wide_kernel")
         for i in range(n):
             exp = oracle.box(Ls[i], Rs[i], win, D, oracle.RAW_LOC)
             assert np.array_equal(out[i], exp), (win, H, W, D, i, np.argwhere(out[i] != exp)[:4])
     L, R = noise_pair(win, win + 20, 200, shift=4, ch=3)
     assert np.array_equal(oa.get_disparity_host(L, R, win, 30), oracle.literal(np.ascontiguousarray(L[:, :, 0]), np.ascontiguousarray(R[:, :, 0]), win, 30))
+
+
+@pytest.mark.parametrize("win", [51, 64, 97, 128, 129, 200, 254, 255])
+def test_wide_windows_column_sum_matcher(win):
+    """sad_wide_kernel, windows of 50..255 columns (the API's maximum): frames one column wider than the window, frames that
+    span several column blocks (257 - win output columns each) and row bands (32 rows), batches, every D class (below 8, not a
+    multiple of 8, 256), saturated costs (binary dots: cost up to win^2 * 255 < 2^24), against the oracle and the brute force."""
+    from helpers import kname
+    for (H, W, n, D, binary) in ((win + 1, win + 1, 1, 5, False), (win + 40, win + 300, 2, 30, True), (win + 33, 2 * (257 - win) + win + 3, 1, 256, False),
+                                  (win + 7, win + 130, 3, 67, True)):
+        Ls, Rs = zip(*[noise_pair(win * 13 + D + i, H, W, shift=min(5 + i, D - 1, W - 1), binary=binary) for i in range(n)])
+        ctx = oa.Context(0)
+        dL, dR = dev(np.stack(Ls)), dev(np.stack(Rs))
+        out = oa.compute_batch_device(dL, dR, win, D, oa.RAW_LOC, ctx=ctx).cpu().numpy()
+        assert kname(ctx) == "sad_wide_kernel"
+        gen = oa.compute_batch_device(dL, dR, win, D, oa.RAW_LOC | oa.FORCE_GENERIC, ctx=ctx).cpu().numpy()
+        assert kname(ctx) == "sad_generic_kernel"
+        for i in range(n):
+            exp = oracle.box(Ls[i], Rs[i], win, D, oracle.RAW_LOC)
+            assert np.array_equal(out[i], exp), (win, H, W, D, i, np.argwhere(out[i] != exp)[:4])
+            assert np.array_equal(gen[i], exp), (win, H, W, D, i)

@@ -16,7 +16,8 @@
 //                              disparities; sad_strip_kernel<WIN,NSLM> (sad_strip.inc: the same work split with every operand
 //                              staged as a ready-made dword in LDS) above; sad_quad_lds_kernel<WIN,KC> (quad_kernels.hip) for
 //                              windows below 4 columns and a few 4-wide cases; sad_quad_kernel<WIN> = the same arithmetic
-//                              with operands through L1 (A/B flag); sad_generic_kernel for win > QUAD_MAXWIN (49).
+//                              with operands through L1 (A/B flag); sad_wide_kernel (column sums) for win > QUAD_MAXWIN (49);
+//                              sad_generic_kernel (brute force) under SADBM_FORCE_GENERIC.
 //
 // The quad matcher lives in quad_kernels.hip, the strip matchers in sad_strip.inc / strip_kernels.hip /
 // strip_otf_kernels.hip (separate translation units so they compile in parallel); sadbm_internal.hpp holds what they share.
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(256) zero_rows_kernel(uint8_t *out, int64_t ou
     for (int b = 0; b < 4 && x + b < cols; ++b) o[b] = 0;
 }
 
-// Brute-force matcher for any window (win > QUAD_MAXWIN or SADBM_FORCE_GENERIC): one thread per output
+// Brute-force matcher for any window (SADBM_FORCE_GENERIC): one thread per output
 // pixel, window SAD with v_sad_u8 on words from the padded planes.  Correctness path, not tuned.
 __global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
 {
@@ -197,79 +198,125 @@ __global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
     out[x] = (p.flags & SADBM_RAW_LOC) ? (uint8_t)loc : (uint8_t)((loc * 16u) & 0xFFu);
 }
 
-// Windows beyond the quad matcher (50..255 columns): O(win) lane-ops per evaluation instead of the brute force's O(win^2 / 4).
-// A block is 256 adjacent columns x WIDE_TY output rows.  Thread t keeps, for eight disparities at a time, the vertical
-// running sums of |L - R| over the window's rows in column XB + t (one row enters and one leaves per step, SAD.cpp:13-22's
-// sum split into columns); each output row the block exchanges them through LDS (double-buffered: one barrier per row) and
-// thread t < NX = 257 - win adds the win columns t .. t+win-1.  The running first-minimum key of every (row, column) lives in
-// a thread-private LDS cell between the passes over the disparity chunks.  cost < 255^3 < 2^24: key = cost << 8 | k.
+// Windows beyond the quad matcher (50..255 columns): O(win / 8) LDS reads and ~30 lane-ops per evaluation instead of the brute
+// force's O(win^2 / 4).  A block is 256 adjacent columns x WIDE_TY output rows x 64 disparities per pass.
+//   1. Thread t keeps the vertical running sums of |L - R| over the window's rows in column XB + t for the 64 disparities
+//      (SAD.cpp:13-22's sum split into columns; <= 255 * 255: packed 16-bit, four per v_mqsad_pk_u16_u8 -- its reference
+//      operand is the L byte alone, the three zero bytes are masked out; an L byte of 0 would be masked too, so those lanes
+//      match 255 against the complemented R bytes).  One row enters and one leaves per step.
+//   2. Per output row and chunk of 8 disparities the block exchanges the sums through LDS: C[t] (packed), then
+//      T[t] = C[t] + .. + C[t+7] (32-bit), then thread t < NX = 257 - win adds T[t], T[t+8], .. and the win % 8 columns left.
+//   3. First-minimum key = cost << 8 | k (cost < 255^3 < 2^24); with D > 64 it waits in a thread-private LDS cell between passes.
 constexpr int WIDE_TY = 32;
+constexpr int WIDE_LDS = (2 * 264 + 2 * 256) * 16;           // C (double-buffered, 8 zero entries behind each) | T
 __global__ void __launch_bounds__(256) sad_wide_kernel(Params p)
 {
-    __shared__ uint4 cs_lo[2][256], cs_hi[2][256];
-    __shared__ uint32_t best_s[WIDE_TY][256];
+    extern __shared__ uint4 wide_lds[];
+    uint4 *const Cs = wide_lds, *const T = wide_lds + 2 * 264;
+    uint32_t *const best_s = (uint32_t *)(wide_lds + 2 * 264 + 2 * 256);      // [WIDE_TY][256], allocated when D > 64
     typedef uint32_t u32u __attribute__((aligned(1)));
     const int tid = threadIdx.x, NX = 257 - p.win;
     const int xc = blockIdx.x * NX + tid;
     const int yb = blockIdx.y * WIDE_TY, ny = min(WIDE_TY, p.nvalid - yb);
     const uint8_t *L = p.L + (int64_t)blockIdx.z * p.plane_stride + (int64_t)yb * p.pitch + xc;
     const uint8_t *R = p.R + (int64_t)blockIdx.z * p.plane_stride + (int64_t)yb * p.pitch + xc;
+    uint8_t *out = p.out + (int64_t)blockIdx.z * p.out_stride + (int64_t)yb * p.out_pitch + xc;
     const int ocols = p.W - p.win;
     const bool col_ok = xc < p.W;                      // columns beyond the frame feed no output column (x + win - 1 < W - 1)
     const bool out_ok = tid < NX && xc < ocols;
-    for (int ry = 0; ry < ny; ++ry) best_s[ry][tid] = KEY_MAX;
+    const int kmax = min(xc, p.D - 1);                 // slots k > column keep cost 0 (SAD.cpp:40 skips them): the x + 1 key below
+    const int nm = p.win >> 3, rem0 = nm << 3;
+    if (tid < 16) Cs[(tid >> 3) * 264 + 256 + (tid & 7)] = make_uint4(0, 0, 0, 0);
     int it = 0;
-    for (int kc = 0; kc < p.D; kc += 8) {
-        uint32_t cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int kg = 0; kg < p.D; kg += 64) {
+        uint32_t cs[8][4];                             // chunk c (k = kg + 8c + j): {j3,j2} {j1,j0} {j7,j6} {j5,j4} as 16-bit pairs
+#pragma unroll
+        for (int c = 0; c < 8; ++c) cs[c][0] = cs[c][1] = cs[c][2] = cs[c][3] = 0;
         for (int r = 0; r < ny + p.win - 1; ++r) {
+            const bool leave = r >= p.win, emit = r >= p.win - 1;
+            uint32_t rw[16], qw[16], lref = 0, mref = 0;
             if (col_ok) {
-                // disparity kc + j pairs L[xc] with R[xc - kc - j]: eight bytes that end at R[xc - kc] (left padding: zeros)
-                const uint8_t *pr = R + (int64_t)r * p.pitch - kc - 7;
-                const uint32_t lb = L[(int64_t)r * p.pitch], r0 = *(const u32u *)pr, r1 = *(const u32u *)(pr + 4);
+                // disparity kg + i pairs L[xc] with R[xc - kg - i]: the 64 bytes that end at R[xc - kg] (left padding: zeros)
+                const uint8_t *pr = R + (int64_t)r * p.pitch - kg - 63;
+                const uint32_t lb = L[(int64_t)r * p.pitch], lm = lb ? 0u : 0xFFFFFFFFu;
+                lref = lb ? lb : 255u;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    cs[j] = __builtin_amdgcn_sad_u8(lb, (r1 >> (8 * (3 - j))) & 0xFFu, cs[j]);
-                    cs[4 + j] = __builtin_amdgcn_sad_u8(lb, (r0 >> (8 * (3 - j))) & 0xFFu, cs[4 + j]);
-                }
-                if (r >= p.win) {
+                for (int i = 0; i < 16; ++i) rw[i] = *(const u32u *)(pr + 4 * i) ^ lm;
+                if (leave) {
                     const uint8_t *qr = pr - (int64_t)p.win * p.pitch;
-                    const uint32_t mb = L[(int64_t)(r - p.win) * p.pitch], q0 = *(const u32u *)qr, q1 = *(const u32u *)(qr + 4);
+                    const uint32_t mb = L[(int64_t)(r - p.win) * p.pitch], mm = mb ? 0u : 0xFFFFFFFFu;
+                    mref = mb ? mb : 255u;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        cs[j] -= __builtin_amdgcn_sad_u8(mb, (q1 >> (8 * (3 - j))) & 0xFFu, 0u);
-                        cs[4 + j] -= __builtin_amdgcn_sad_u8(mb, (q0 >> (8 * (3 - j))) & 0xFFu, 0u);
+                    for (int i = 0; i < 16; ++i) qw[i] = *(const u32u *)(qr + 4 * i) ^ mm;
+                }
+            }
+            uint32_t b = KEY_MAX;
+            if (emit && out_ok && kg > 0) b = best_s[(r - (p.win - 1)) * 256 + tid];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (kg + 8 * c < p.D) {                // uniform over the block
+                    if (col_ok) {
+                        // word 15 - 2c holds j = 3..0 in bytes 0..3, word 14 - 2c holds j = 7..4
+                        uint64_t a1 = (uint64_t)cs[c][0] | ((uint64_t)cs[c][1] << 32), a0 = (uint64_t)cs[c][2] | ((uint64_t)cs[c][3] << 32);
+                        a1 = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)rw[15 - 2 * c], lref, a1);
+                        a0 = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)rw[14 - 2 * c], lref, a0);
+                        cs[c][0] = (uint32_t)a1; cs[c][1] = (uint32_t)(a1 >> 32); cs[c][2] = (uint32_t)a0; cs[c][3] = (uint32_t)(a0 >> 32);
+                        if (leave) {                   // every 16-bit sum holds the leaving row's share: no borrow crosses a field
+                            const uint64_t d1 = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)qw[15 - 2 * c], mref, 0ull);
+                            const uint64_t d0 = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)qw[14 - 2 * c], mref, 0ull);
+                            cs[c][0] -= (uint32_t)d1; cs[c][1] -= (uint32_t)(d1 >> 32); cs[c][2] -= (uint32_t)d0; cs[c][3] -= (uint32_t)(d0 >> 32);
+                        }
+                    }
+                    if (emit) {
+                        uint4 *const C = Cs + it * 264;
+                        C[tid] = make_uint4(cs[c][0], cs[c][1], cs[c][2], cs[c][3]);
+                        __syncthreads();
+                        uint32_t t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const uint4 u = C[tid + i];            // <= 263: zero entries behind the 256 columns
+                            t8[0] += u.x & 0xFFFFu; t8[1] += u.x >> 16; t8[2] += u.y & 0xFFFFu; t8[3] += u.y >> 16;
+                            t8[4] += u.z & 0xFFFFu; t8[5] += u.z >> 16; t8[6] += u.w & 0xFFFFu; t8[7] += u.w >> 16;
+                        }
+                        T[tid] = make_uint4(t8[0], t8[1], t8[2], t8[3]);
+                        T[256 + tid] = make_uint4(t8[4], t8[5], t8[6], t8[7]);
+                        __syncthreads();
+                        if (out_ok) {
+                            uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                            for (int m = 0; m < nm; ++m) {         // tid + 8m + 7 <= tid + win - 1 <= 255
+                                const uint4 u = T[tid + 8 * m], v = T[256 + tid + 8 * m];
+                                a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w;
+                                a[4] += v.x; a[5] += v.y; a[6] += v.z; a[7] += v.w;
+                            }
+                            for (int i = rem0; i < p.win; ++i) {
+                                const uint4 u = C[tid + i];
+                                a[0] += u.x & 0xFFFFu; a[1] += u.x >> 16; a[2] += u.y & 0xFFFFu; a[3] += u.y >> 16;
+                                a[4] += u.z & 0xFFFFu; a[5] += u.z >> 16; a[6] += u.w & 0xFFFFu; a[7] += u.w >> 16;
+                            }
+                            const int k0 = kg + 8 * c;
+                            // ascending k (ties keep the first minimum through the key's low byte anyway)
+                            if (k0 + 0 <= kmax) b = min(b, (a[3] << 8) | (uint32_t)(k0 + 0));
+                            if (k0 + 1 <= kmax) b = min(b, (a[2] << 8) | (uint32_t)(k0 + 1));
+                            if (k0 + 2 <= kmax) b = min(b, (a[1] << 8) | (uint32_t)(k0 + 2));
+                            if (k0 + 3 <= kmax) b = min(b, (a[0] << 8) | (uint32_t)(k0 + 3));
+                            if (k0 + 4 <= kmax) b = min(b, (a[7] << 8) | (uint32_t)(k0 + 4));
+                            if (k0 + 5 <= kmax) b = min(b, (a[6] << 8) | (uint32_t)(k0 + 5));
+                            if (k0 + 6 <= kmax) b = min(b, (a[5] << 8) | (uint32_t)(k0 + 6));
+                            if (k0 + 7 <= kmax) b = min(b, (a[4] << 8) | (uint32_t)(k0 + 7));
+                        }
+                        it ^= 1;
                     }
                 }
             }
-            if (r >= p.win - 1) {                      // uniform over the block
-                cs_lo[it][tid] = make_uint4(cs[0], cs[1], cs[2], cs[3]);
-                cs_hi[it][tid] = make_uint4(cs[4], cs[5], cs[6], cs[7]);
-                __syncthreads();
-                if (out_ok) {
-                    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    for (int i = 0; i < p.win; ++i) {
-                        const uint4 u = cs_lo[it][tid + i], v = cs_hi[it][tid + i];      // tid + i <= NX - 1 + win - 1 = 255
-                        a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w;
-                        a[4] += v.x; a[5] += v.y; a[6] += v.z; a[7] += v.w;
-                    }
-                    uint32_t b = best_s[r - (p.win - 1)][tid];
-                    const int kmax = min(xc, p.D - 1);          // slots k > column keep cost 0 (SAD.cpp:40 skips them): added below
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (kc + j <= kmax) b = min(b, (a[j] << 8) | (uint32_t)(kc + j));
-                    best_s[r - (p.win - 1)][tid] = b;
+            if (emit && tid < NX && xc < p.W) {
+                if (kg + 64 < p.D) {
+                    if (out_ok) best_s[(r - (p.win - 1)) * 256 + tid] = b;
+                } else {
+                    if (xc + 1 < p.D) b = min(b, (uint32_t)(xc + 1));
+                    const uint32_t loc = b & 0xFFu;
+                    out[(int64_t)(r - (p.win - 1)) * p.out_pitch] = !out_ok ? (uint8_t)0 : (p.flags & SADBM_RAW_LOC) ? (uint8_t)loc : (uint8_t)((loc * 16u) & 0xFFu);
                 }
-                it ^= 1;
             }
-        }
-    }
-    if (tid < NX && xc < p.W) {
-        uint8_t *out = p.out + (int64_t)blockIdx.z * p.out_stride + (int64_t)yb * p.out_pitch + xc;
-        for (int ry = 0; ry < ny; ++ry) {
-            uint32_t b = best_s[ry][tid];
-            if (xc + 1 < p.D) b = min(b, (uint32_t)(xc + 1));
-            const uint32_t loc = b & 0xFFu;
-            out[(int64_t)ry * p.out_pitch] = xc >= ocols ? (uint8_t)0 : (p.flags & SADBM_RAW_LOC) ? (uint8_t)loc : (uint8_t)((loc * 16u) & 0xFFu);
         }
     }
 }
@@ -835,7 +882,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         const int NX = 257 - win;                                // output columns per block (win <= 255)
         dim3 g((cols + NX - 1) / NX, (nvalid + WIDE_TY - 1) / WIDE_TY, n_pairs);
         if (g.y > 65535u || g.z > 65535u) return SADBM_E_SIZE;
-        hipLaunchKernelGGL(sad_wide_kernel, g, dim3(256), 0, st, p);
+        hipLaunchKernelGGL(sad_wide_kernel, g, dim3(256), (size_t)WIDE_LDS + (D > 64 ? (size_t)WIDE_TY * 256 * 4 : 0), st, p);
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_wide_kernel");
     } else if ((win > MAXWIN && (flags & SADBM_KERNEL_GLOBAL)) || (flags & SADBM_FORCE_GENERIC)) {
         dim3 g((cols + 255) / 256, nvalid, n_pairs);

@@ -46,6 +46,33 @@ def test_random_batches_match_oracle(chunk):
             assert (got[:, :, :pad // 2] == 0xAB).all() and (got[:, :, pad // 2 + W:] == 0xAB).all()
 
 
+@pytest.mark.parametrize("chunk", range(2))
+def test_random_wide_windows_match_oracle(chunk):
+    """The same bar for windows of 50..255 columns (sad_wide_kernel): frames narrower, as wide as and a few column blocks wider than
+    the window, 1/3/4 channels, pitched outputs whose padding must stay untouched."""
+    import torch
+    rng = np.random.default_rng(77 + chunk)
+    for case in range(14):
+        win = int(rng.choice([50, 51, 63, 64, 65, 100, 128, 177, 254, 255, int(rng.integers(50, 256))]))
+        D = int(rng.choice([1, 7, 8, 9, 30, 63, 64, 65, 100, 128, 129, 200, 256]))
+        H = int(rng.choice([win - 3, win, win + 1, win + int(rng.integers(2, 70))]))
+        W = int(rng.choice([win, win + 1, win + int(rng.integers(2, 40)), win + int(rng.integers(40, 700))]))
+        pairs, ch, pad = int(rng.choice([1, 2, 5])), int(rng.choice([1, 1, 3, 4])), int(rng.choice([0, 3, 16]))
+        flags = int(rng.choice([0, oa.RAW_LOC]))
+        Ls, Rs = zip(*[noise_pair(31 * case + i + 500 * chunk, H, W, shift=1 + (i + case) % 9, binary=(case % 3 == 2), ch=ch) for i in range(pairs)])
+        obuf = torch.full((pairs, H, W + pad), 0xAB, dtype=torch.uint8, device="cuda")
+        out = obuf[:, :, pad // 2: pad // 2 + W] if pad else obuf
+        oa.compute_batch_device(torch.from_numpy(np.stack(Ls)).cuda(), torch.from_numpy(np.stack(Rs)).cuda(), win, D, flags, out=out)
+        got = obuf.cpu().numpy()
+        for i in range(pairs):
+            Li, Ri = (Ls[i], Rs[i]) if ch == 1 else (np.ascontiguousarray(Ls[i][:, :, 0]), np.ascontiguousarray(Rs[i][:, :, 0]))
+            exp = oracle.box(Li, Ri, win, D, oracle.RAW_LOC if (flags & oa.RAW_LOC) else 0)
+            bad = np.argwhere(got[i, :, pad // 2: pad // 2 + W] != exp)
+            assert bad.size == 0, ((win, D, H, W, pairs, ch, flags, pad), i, len(bad), bad[:5])
+        if pad:
+            assert (got[:, :, :pad // 2] == 0xAB).all() and (got[:, :, pad // 2 + W:] == 0xAB).all()
+
+
 def test_very_wide_frame_and_many_tiny_frames():
     """Frames wider than the strip matcher's 16-bit column fields fall back to the quad matcher; hundreds of tiny frames
     go into wide plane groups."""

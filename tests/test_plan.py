@@ -21,7 +21,9 @@ def test_baseline_configurations_get_the_documented_kernels():
     assert p["kernel"] == "sad_strip_kernel<7>" and p["FG"] == 8 and p["Wp"] == 1248 and p["bx"] == 39
     assert oa.plan(1080, 1920, 1, 1, 3, 30)["matcher"] == "quad"
     assert oa.plan(100, 100, 1, 1, 31, 30)["kernel"] == "sad_quad_lds_kernel<31,8>"       # 26 ... 49: the quad matcher (no strip instantiation)
-    assert oa.plan(100, 100, 1, 1, 50, 30)["matcher"] == "generic"
+    assert oa.plan(100, 100, 1, 1, 50, 30)["matcher"] == "wide"
+    assert oa.plan(300, 300, 1, 1, 255, 30)["kernel"] == "sad_wide_kernel"
+    assert oa.plan(100, 100, 1, 1, 50, 30, oa.FORCE_GENERIC)["matcher"] == "generic"
     assert oa.plan(7, 100, 1, 1, 7, 30)["matcher"] == "none"        # rows <= winSize: all-zero result, nothing to launch
     assert oa.plan(1080, 1920, 1, 1, 7, 30, oa.KERNEL_QUAD)["kernel"] == "sad_quad_lds_kernel<7,8>"
     assert oa.plan(1080, 1920, 1, 32, 7, 100)["kernel"] == "sad_strip_otf_kernel<7,8>"     # D % 16 != 0 up to 128: poisoned sums

@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
 }
 
 // Windows beyond the quad matcher (50..255 columns): O(win / 8) LDS reads and ~30 lane-ops per evaluation instead of the brute
-// force's O(win^2 / 4).  A block is 256 adjacent columns x WIDE_TY output rows x 64 disparities per pass.
+// force's O(win^2 / 4).  A block is 256 adjacent columns x 8 or 16 output rows (at most WIDE_TY) x 64 disparities per pass.
 //   1. Thread t keeps the vertical running sums of |L - R| over the window's rows in column XB + t for the 64 disparities
 //      (SAD.cpp:13-22's sum split into columns; <= 255 * 255: packed 16-bit, four per v_mqsad_pk_u16_u8 -- its reference
 //      operand is the L byte alone, the three zero bytes are masked out; an L byte of 0 would be masked too, so those lanes
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) sad_wide_kernel(Params p)
     typedef uint32_t u32u __attribute__((aligned(1)));
     const int tid = threadIdx.x, NX = 257 - p.win;
     const int xc = blockIdx.x * NX + tid;
-    const int yb = blockIdx.y * WIDE_TY, ny = min(WIDE_TY, p.nvalid - yb);
+    const int yb = blockIdx.y * p.TY, ny = min(p.TY, p.nvalid - yb);           // p.TY <= WIDE_TY
     const uint8_t *L = p.L + (int64_t)blockIdx.z * p.plane_stride + (int64_t)yb * p.pitch + xc;
     const uint8_t *R = p.R + (int64_t)blockIdx.z * p.plane_stride + (int64_t)yb * p.pitch + xc;
     uint8_t *out = p.out + (int64_t)blockIdx.z * p.out_stride + (int64_t)yb * p.out_pitch + xc;
@@ -880,7 +880,13 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
 
     if (win > QUAD_MAXWIN && !(flags & SADBM_FORCE_GENERIC)) {
         const int NX = 257 - win;                                // output columns per block (win <= 255)
-        dim3 g((cols + NX - 1) / NX, (nvalid + WIDE_TY - 1) / WIDE_TY, n_pairs);
+        // rows per block: every block sums win - 1 rows before its first output row, but a grid below a few blocks per CU
+        // leaves the loads' and the exchanges' latency exposed (profiles/r02l_wide_windows.txt)
+        int TY = 16;                                             // 16 measured 1-2 % ahead of 32 on large jobs too
+        if ((long)((cols + NX - 1) / NX) * ((nvalid + TY - 1) / TY) * n_pairs < 3L * ctx->cus / 2) TY = 8;
+        if (env().strip_ty) TY = env().strip_ty < WIDE_TY ? env().strip_ty : WIDE_TY;
+        p.TY = TY;
+        dim3 g((cols + NX - 1) / NX, (nvalid + TY - 1) / TY, n_pairs);
         if (g.y > 65535u || g.z > 65535u) return SADBM_E_SIZE;
         hipLaunchKernelGGL(sad_wide_kernel, g, dim3(256), (size_t)WIDE_LDS + (D > 64 ? (size_t)WIDE_TY * 256 * 4 : 0), st, p);
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_wide_kernel");

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off parity soak on the GPU box: random large-ish batches (several column blocks, bands and plane groups) against the
-oracle.  tools/soak.py [cases] [seed]   -- prints one line per case, exits non-zero on the first mismatch."""
+oracle.  tools/soak.py [cases] [seed] [wide]   (wide: windows of 26..255 columns)   -- prints one line per case, exits non-zero on the first mismatch."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,12 +10,15 @@ import oracle
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
 t0 = time.time()
 for case in range(n):
     win = int(rng.integers(4, 26)) if rng.random() < 0.85 else int(rng.choice([1, 2, 3, 26, 29, 31]))
     D = int(rng.choice([8, 16, 24, 30, 32, 33, 48, 64, 65, 100, 128, 129, 192, 255, 256]))
     W = int(rng.choice([int(rng.integers(300, 1300)), int(rng.integers(1300, 4200)), int(rng.integers(40, 300)), 1920, 1242, 2048, 640, 384, 450]))
-    H = int(rng.integers(win + 2, 420))
+    if wide:
+        win = int(rng.integers(26, 256))
+    H = int(rng.integers(win + 2, win + 200 if wide else 420))
     pairs = int(rng.choice([1, 2, 3, 5, 9]))
     flags = int(rng.choice([0, 0, oa.KERNEL_STRIP, oa.KERNEL_QUAD])) | int(rng.choice([0, oa.RAW_LOC]))
     Ls, Rs = [], []
@@ -37,5 +40,5 @@ for case in range(n):
             bad = np.argwhere(out[i] != exp)
             print("MISMATCH", case, (win, D, W, H, pairs, flags), i, len(bad), bad[:5], flush=True)
             sys.exit(1)
-    print("ok %3d win=%2d D=%3d %4dx%3d pairs=%d flags=%2d %s  t=%.0fs" % (case, win, D, W, H, pairs, flags, ctx.last_kernel(), time.time() - t0), flush=True)
+    print("ok %3d win=%3d D=%3d %4dx%3d pairs=%d flags=%2d %s  t=%.0fs" % (case, win, D, W, H, pairs, flags, ctx.last_kernel(), time.time() - t0), flush=True)
 print("soak passed:", n, "cases")

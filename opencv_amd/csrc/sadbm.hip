@@ -544,6 +544,7 @@ struct EnvKnobs {
     int tail = -1;               // SADBM_TAIL       on-the-fly kernels: units per XCD split into half-height blocks at the end of the launch (-1 choose, 0 none)
     int trace = 0;               // SADBM_TRACE      1: one line per matcher launch on stderr (kernel, grid shape)
     int direct = -1;             // SADBM_DIRECT     on-the-fly form reading the caller's 1-channel images itself (no prep pass): -1 choose, 0 never, 1 whenever possible
+    int wide_from = QUAD_MAXWIN + 1;   // SADBM_WIDE_FROM  narrowest window of sad_wide_kernel (26 .. 50; the quad matcher serves the ones below)
     long zc_bytes = 1 << 20;     // SADBM_ZEROCOPY_BYTES  host API: inputs up to this size are read by the GPU from pinned host memory
 };
 EnvKnobs read_env()
@@ -561,6 +562,7 @@ EnvKnobs read_env()
     k.trace = geti("SADBM_TRACE", 0);
     k.direct = geti("SADBM_DIRECT", -1); if (k.direct < 0 || k.direct > 1) k.direct = -1;
     k.otf_ng = geti("SADBM_OTF_NG", 0); if (k.otf_ng != 1 && k.otf_ng != 2 && k.otf_ng != 4 && k.otf_ng != 8) k.otf_ng = 0;
+    k.wide_from = geti("SADBM_WIDE_FROM", QUAD_MAXWIN + 1); if (k.wide_from <= MAXWIN || k.wide_from > QUAD_MAXWIN + 1) k.wide_from = QUAD_MAXWIN + 1;
     if (const char *e = getenv("SADBM_ZEROCOPY_BYTES")) k.zc_bytes = atol(e);
     return k;
 }
@@ -878,7 +880,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         return SADBM_OK;
     }
 
-    if (win > QUAD_MAXWIN && !(flags & SADBM_FORCE_GENERIC)) {
+    if (win >= env().wide_from && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL))) {
         const int NX = 257 - win;                                // output columns per block (win <= 255)
         // rows per block: every block sums win - 1 rows before its first output row, but a grid below a few blocks per CU
         // leaves the loads' and the exchanges' latency exposed (profiles/r02l_wide_windows.txt)
@@ -1064,7 +1066,7 @@ int sadbm_plan_describe(int rows, int cols, int channels, int n_pairs, int win, 
         snprintf(text, (size_t)text_len, "matcher=%s kernel=%s threads=%d FG=%d Wp=%d groups=%d bx=%d TY=%d nby=%d blocks=%ld tail=%d lds=%zu scratch=%zu prep=%d",
                  sp.use_otf ? "strip_otf" : "strip", name, 64 * sp.ng, sp.FG, sp.Wp, sp.n_groups, sp.bx, sp.TY, sp.nby, sp.nblocks, sp.tail, sp.lds,
                  sp.direct ? (size_t)0 : sp.planes_need, sp.direct ? 0 : 1);
-    } else if (win > QUAD_MAXWIN && !(flags & SADBM_FORCE_GENERIC)) {
+    } else if (win >= env().wide_from && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL))) {
         snprintf(text, (size_t)text_len, "matcher=wide kernel=sad_wide_kernel scratch=%zu prep=1", sp.planes_need);
     } else if ((win > MAXWIN && (flags & SADBM_KERNEL_GLOBAL)) || (flags & SADBM_FORCE_GENERIC)) {
         snprintf(text, (size_t)text_len, "matcher=generic kernel=sad_generic_kernel scratch=%zu prep=1", sp.planes_need);

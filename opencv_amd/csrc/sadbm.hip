@@ -198,22 +198,34 @@ __global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
     out[x] = (p.flags & SADBM_RAW_LOC) ? (uint8_t)loc : (uint8_t)((loc * 16u) & 0xFFu);
 }
 
-// Windows beyond the quad matcher (50..255 columns): O(win / 8) LDS reads and ~30 lane-ops per evaluation instead of the brute
-// force's O(win^2 / 4).  A block is 256 adjacent columns x 8 or 16 output rows (at most WIDE_TY) x 64 disparities per pass.
+// Inclusive prefix sum over the 64 lanes of a wave (row_shr 1, 2, 4, 8 inside the rows of 16, then the gfx9 row broadcasts).
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// Windows beyond the quad matcher (50..255 columns): ~25 lane-ops per evaluation whatever the window, instead of the brute
+// force's O(win^2 / 4).  A block is 256 adjacent columns x 8, 16 or 32 output rows x 64 disparities per pass.
 //   1. Thread t keeps the vertical running sums of |L - R| over the window's rows in column XB + t for the 64 disparities
 //      (SAD.cpp:13-22's sum split into columns; <= 255 * 255: packed 16-bit, four per v_mqsad_pk_u16_u8 -- its reference
 //      operand is the L byte alone, the three zero bytes are masked out; an L byte of 0 would be masked too, so those lanes
 //      match 255 against the complemented R bytes).  One row enters and one leaves per step.
-//   2. Per output row and chunk of 8 disparities the block exchanges the sums through LDS: C[t] (packed), then
-//      T[t] = C[t] + .. + C[t+7] (32-bit), then thread t < NX = 257 - win adds T[t], T[t+8], .. and the win % 8 columns left.
+//   2. Per output row and 16 disparities the block turns the sums into prefix sums P over its 256 columns (DPP scan
+//      in each wave, wave totals and P through LDS); thread t < NX = 257 - win takes P[t + win - 1] - P[t - 1].
 //   3. First-minimum key = cost << 8 | k (cost < 255^3 < 2^24); with D > 64 it waits in a thread-private LDS cell between passes.
 constexpr int WIDE_TY = 32;
-constexpr int WIDE_LDS = (2 * 264 + 2 * 256) * 16;           // C (double-buffered, 8 zero entries behind each) | T
+constexpr int WIDE_LDS = (4 * 256 + 16) * 16;                // prefix sums | wave totals
 __global__ void __launch_bounds__(256) sad_wide_kernel(Params p)
 {
     extern __shared__ uint4 wide_lds[];
-    uint4 *const Cs = wide_lds, *const T = wide_lds + 2 * 264;
-    uint32_t *const best_s = (uint32_t *)(wide_lds + 2 * 264 + 2 * 256);      // [WIDE_TY][256], allocated when D > 64
+    uint4 *const P = wide_lds, *const Wt = wide_lds + 4 * 256;                  // prefix sums [4 quarters][256] | wave totals [4 quarters][4]
+    uint32_t *const best_s = (uint32_t *)(wide_lds + 4 * 256 + 16);             // [WIDE_TY][256], allocated when D > 64
     typedef uint32_t u32u __attribute__((aligned(1)));
     const int tid = threadIdx.x, NX = 257 - p.win;
     const int xc = blockIdx.x * NX + tid;
@@ -225,9 +237,7 @@ __global__ void __launch_bounds__(256) sad_wide_kernel(Params p)
     const bool col_ok = xc < p.W;                      // columns beyond the frame feed no output column (x + win - 1 < W - 1)
     const bool out_ok = tid < NX && xc < ocols;
     const int kmax = min(xc, p.D - 1);                 // slots k > column keep cost 0 (SAD.cpp:40 skips them): the x + 1 key below
-    const int nm = p.win >> 3, rem0 = nm << 3;
-    if (tid < 16) Cs[(tid >> 3) * 264 + 256 + (tid & 7)] = make_uint4(0, 0, 0, 0);
-    int it = 0;
+    const int lane = tid & 63, wave = tid >> 6;
     for (int kg = 0; kg < p.D; kg += 64) {
         uint32_t cs[8][4];                             // chunk c (k = kg + 8c + j): {j3,j2} {j1,j0} {j7,j6} {j5,j4} as 16-bit pairs
 #pragma unroll
@@ -253,58 +263,72 @@ __global__ void __launch_bounds__(256) sad_wide_kernel(Params p)
             uint32_t b = KEY_MAX;
             if (emit && out_ok && kg > 0) b = best_s[(r - (p.win - 1)) * 256 + tid];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                if (kg + 8 * c < p.D) {                // uniform over the block
+            for (int c2 = 0; c2 < 4; ++c2) {           // two chunks of 8 disparities per exchange
+                if (kg + 16 * c2 < p.D) {              // uniform over the block (slots >= D of the pair are summed but never compete)
                     if (col_ok) {
-                        // word 15 - 2c holds j = 3..0 in bytes 0..3, word 14 - 2c holds j = 7..4
-                        uint64_t a1 = (uint64_t)cs[c][0] | ((uint64_t)cs[c][1] << 32), a0 = (uint64_t)cs[c][2] | ((uint64_t)cs[c][3] << 32);
-                        a1 = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)rw[15 - 2 * c], lref, a1);
-                        a0 = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)rw[14 - 2 * c], lref, a0);
-                        cs[c][0] = (uint32_t)a1; cs[c][1] = (uint32_t)(a1 >> 32); cs[c][2] = (uint32_t)a0; cs[c][3] = (uint32_t)(a0 >> 32);
-                        if (leave) {                   // every 16-bit sum holds the leaving row's share: no borrow crosses a field
-                            const uint64_t d1 = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)qw[15 - 2 * c], mref, 0ull);
-                            const uint64_t d0 = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)qw[14 - 2 * c], mref, 0ull);
-                            cs[c][0] -= (uint32_t)d1; cs[c][1] -= (uint32_t)(d1 >> 32); cs[c][2] -= (uint32_t)d0; cs[c][3] -= (uint32_t)(d0 >> 32);
+#pragma unroll
+                        for (int c = 2 * c2; c < 2 * c2 + 2; ++c) {
+                            // word 15 - 2c holds j = 3..0 in bytes 0..3, word 14 - 2c holds j = 7..4
+                            uint64_t a1 = (uint64_t)cs[c][0] | ((uint64_t)cs[c][1] << 32), a0 = (uint64_t)cs[c][2] | ((uint64_t)cs[c][3] << 32);
+                            a1 = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)rw[15 - 2 * c], lref, a1);
+                            a0 = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)rw[14 - 2 * c], lref, a0);
+                            cs[c][0] = (uint32_t)a1; cs[c][1] = (uint32_t)(a1 >> 32); cs[c][2] = (uint32_t)a0; cs[c][3] = (uint32_t)(a0 >> 32);
+                            if (leave) {               // every 16-bit sum holds the leaving row's share: no borrow crosses a field
+                                const uint64_t d1 = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)qw[15 - 2 * c], mref, 0ull);
+                                const uint64_t d0 = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)qw[14 - 2 * c], mref, 0ull);
+                                cs[c][0] -= (uint32_t)d1; cs[c][1] -= (uint32_t)(d1 >> 32); cs[c][2] -= (uint32_t)d0; cs[c][3] -= (uint32_t)(d0 >> 32);
+                            }
                         }
                     }
                     if (emit) {
-                        uint4 *const C = Cs + it * 264;
-                        C[tid] = make_uint4(cs[c][0], cs[c][1], cs[c][2], cs[c][3]);
-                        __syncthreads();
-                        uint32_t t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        // prefix sums over the block's 256 columns, 16 disparities at a time: DPP scan inside the wave, wave totals
+                        // through LDS; the window sum of column x is then P[x + win - 1] - P[x - 1]  (P < 256 * 65025 < 2^24)
+                        uint32_t v[16];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const uint4 u = C[tid + i];            // <= 263: zero entries behind the 256 columns
-                            t8[0] += u.x & 0xFFFFu; t8[1] += u.x >> 16; t8[2] += u.y & 0xFFFFu; t8[3] += u.y >> 16;
-                            t8[4] += u.z & 0xFFFFu; t8[5] += u.z >> 16; t8[6] += u.w & 0xFFFFu; t8[7] += u.w >> 16;
+                        for (int q = 0; q < 8; ++q) {
+                            const uint32_t w = cs[2 * c2 + (q >> 2)][q & 3];
+                            v[2 * q] = wave_scan_add(w & 0xFFFFu); v[2 * q + 1] = wave_scan_add(w >> 16);
                         }
-                        T[tid] = make_uint4(t8[0], t8[1], t8[2], t8[3]);
-                        T[256 + tid] = make_uint4(t8[4], t8[5], t8[6], t8[7]);
+                        if (lane == 63) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) Wt[4 * q + wave] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                        }
+                        __syncthreads();
+                        for (int w = 0; w < wave; ++w) {           // wave-uniform
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const uint4 u = Wt[4 * q + w];
+                                v[4 * q] += u.x; v[4 * q + 1] += u.y; v[4 * q + 2] += u.z; v[4 * q + 3] += u.w;
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) P[256 * q + tid] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
                         __syncthreads();
                         if (out_ok) {
-                            uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                            for (int m = 0; m < nm; ++m) {         // tid + 8m + 7 <= tid + win - 1 <= 255
-                                const uint4 u = T[tid + 8 * m], v = T[256 + tid + 8 * m];
-                                a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w;
-                                a[4] += v.x; a[5] += v.y; a[6] += v.z; a[7] += v.w;
+                            uint32_t a[16];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const uint4 u = P[256 * q + tid + p.win - 1];                      // tid + win - 1 <= 255
+                                a[4 * q] = u.x; a[4 * q + 1] = u.y; a[4 * q + 2] = u.z; a[4 * q + 3] = u.w;
                             }
-                            for (int i = rem0; i < p.win; ++i) {
-                                const uint4 u = C[tid + i];
-                                a[0] += u.x & 0xFFFFu; a[1] += u.x >> 16; a[2] += u.y & 0xFFFFu; a[3] += u.y >> 16;
-                                a[4] += u.z & 0xFFFFu; a[5] += u.z >> 16; a[6] += u.w & 0xFFFFu; a[7] += u.w >> 16;
+                            if (tid > 0) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const uint4 u = P[256 * q + tid - 1];
+                                    a[4 * q] -= u.x; a[4 * q + 1] -= u.y; a[4 * q + 2] -= u.z; a[4 * q + 3] -= u.w;
+                                }
                             }
-                            const int k0 = kg + 8 * c;
-                            // ascending k (ties keep the first minimum through the key's low byte anyway)
-                            if (k0 + 0 <= kmax) b = min(b, (a[3] << 8) | (uint32_t)(k0 + 0));
-                            if (k0 + 1 <= kmax) b = min(b, (a[2] << 8) | (uint32_t)(k0 + 1));
-                            if (k0 + 2 <= kmax) b = min(b, (a[1] << 8) | (uint32_t)(k0 + 2));
-                            if (k0 + 3 <= kmax) b = min(b, (a[0] << 8) | (uint32_t)(k0 + 3));
-                            if (k0 + 4 <= kmax) b = min(b, (a[7] << 8) | (uint32_t)(k0 + 4));
-                            if (k0 + 5 <= kmax) b = min(b, (a[6] << 8) | (uint32_t)(k0 + 5));
-                            if (k0 + 6 <= kmax) b = min(b, (a[5] << 8) | (uint32_t)(k0 + 6));
-                            if (k0 + 7 <= kmax) b = min(b, (a[4] << 8) | (uint32_t)(k0 + 7));
+                            // ascending k; a[8h + s]: slot s of chunk 2 c2 + h, slots {j3, j2, j1, j0, j7, j6, j5, j4}
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const int k0 = kg + 16 * c2 + 8 * h;
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) {
+                                    const int sidx = 8 * h + (j < 4 ? 3 - j : 11 - j);
+                                    if (k0 + j <= kmax) b = min(b, (a[sidx] << 8) | (uint32_t)(k0 + j));
+                                }
+                            }
                         }
-                        it ^= 1;
                     }
                 }
             }
@@ -884,8 +908,8 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         const int NX = 257 - win;                                // output columns per block (win <= 255)
         // rows per block: every block sums win - 1 rows before its first output row, but a grid below a few blocks per CU
         // leaves the loads' and the exchanges' latency exposed (profiles/r02l_wide_windows.txt)
-        int TY = 16;                                             // 16 measured 1-2 % ahead of 32 on large jobs too
-        if ((long)((cols + NX - 1) / NX) * ((nvalid + TY - 1) / TY) * n_pairs < 3L * ctx->cus / 2) TY = 8;
+        int TY = WIDE_TY;                                        // the tallest of 32, 16, 8 that still gives 1.5 blocks per CU
+        while (TY > 8 && (long)((cols + NX - 1) / NX) * ((nvalid + TY - 1) / TY) * n_pairs < 3L * ctx->cus / 2) TY >>= 1;
         if (env().strip_ty) TY = env().strip_ty < WIDE_TY ? env().strip_ty : WIDE_TY;
         p.TY = TY;
         dim3 g((cols + NX - 1) / NX, (nvalid + TY - 1) / TY, n_pairs);

@@ -47,6 +47,7 @@ WORKLOADS = {
     "cfg3c_4k_w7_d32": (3840, 2160, 7, 32, 3, 4, 24, 32),
     "cfg4_8k_w21_d256": (7680, 4320, 21, 256, 4, 32, 200, 4),
     "cfg5_kitti_w7_d128": (1242, 375, 7, 128, 1000, 5, 60, 512),
+    "wide_1080p_w51_d64": (1920, 1080, 51, 64, 2, 8, 40, 16),      # beyond the strip / quad matchers: sad_wide_kernel (profiling only)
 }
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # VALU issue, lane-ops/s = 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / (cycles per wave64 instruction and SIMD):

@@ -306,3 +306,11 @@ def test_wide_windows_column_sum_matcher(win):
             exp = oracle.box(Ls[i], Rs[i], win, D, oracle.RAW_LOC)
             assert np.array_equal(out[i], exp), (win, H, W, D, i, np.argwhere(out[i] != exp)[:4])
             assert np.array_equal(gen[i], exp), (win, H, W, D, i)
+    # a row band of a larger frame (what one GPU of sadbm_compute_multi computes), the bottom band included: zero rows below rows - win
+    H, W, D = win + 50, win + 90, 40
+    L, R = noise_pair(win, H, W, shift=6)
+    full = oracle.box(L, R, win, D)
+    for r0, nb in ((0, 20), (20, 17), (37, H - 37)):
+        i1 = min(r0 + nb + win - 1, H)
+        got = oa.compute_band_device(dev(L[r0:i1]), dev(R[r0:i1]), H, r0, nb, win, D).cpu().numpy()
+        assert np.array_equal(got, full[r0:r0 + nb]), (win, r0, nb)

@@ -74,7 +74,7 @@ struct OG {
 // One image row folded into the running sums of this thread (ADD: entering row, SUB: leaving row).
 //   pL: LP + 4*strip; pR: this thread's first R word in RP[c] (one slot below the slot of its (strip, group))
 template <int WIN, int NG_, bool DIRECT, bool SUB>
-__device__ __forceinline__ void strip_pass_otf(const uint32_t *pL, const uint32_t *pR, uint32_t (&V)[4][SG<WIN>::NV], uint32_t (&E)[4][4][2])
+__device__ __forceinline__ void strip_pass_otf(const uint32_t *pL, const uint32_t *pR, uint32_t (&V)[SG<WIN>::VT][SG<WIN>::NV], uint32_t (&E)[4][4][2])
 {
     using G = SG<WIN>;
     using O = OG<WIN, NG_, DIRECT>;
@@ -84,15 +84,28 @@ __device__ __forceinline__ void strip_pass_otf(const uint32_t *pL, const uint32_
     for (int nb = 0; nb < O::NLWP; nb += 4) lds128(pL + nb, &lw[nb]);
 #pragma unroll
     for (int nb = 0; nb < O::NRWP; nb += 4) lds128(pR + nb, &rw[nb]);
-    // ---- V: whole words ----
+    // ---- V: whole words (packed V: disparities t = 2 tp and 2 tp + 1 share a register, see SG::PKV) ----
+    if constexpr (G::PKV) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            const uint32_t r = rw[n - t + 4];
-            if constexpr (!SUB) V[t][n] = G::HI16 ? __builtin_amdgcn_sad_hi_u8(lw[n], r, V[t][n]) : __builtin_amdgcn_sad_u8(lw[n], r, V[t][n]);
-            else V[t][n] -= G::HI16 ? __builtin_amdgcn_sad_hi_u8(lw[n], r, 0u) : __builtin_amdgcn_sad_u8(lw[n], r, 0u);
-        }
+            for (int n = 0; n < NV; ++n) {
+                uint32_t v = SUB ? 0u : V[tp][n];
+                v = __builtin_amdgcn_sad_u8(lw[n], rw[n - 2 * tp + 4], v);
+                v = __builtin_amdgcn_sad_hi_u8(lw[n], rw[n - 2 * tp + 3], v);
+                if constexpr (!SUB) V[tp][n] = v;
+                else V[tp][n] -= v;
+            }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const uint32_t r = rw[n - t + 4];
+                if constexpr (!SUB) V[t][n] = G::HI16 ? __builtin_amdgcn_sad_hi_u8(lw[n], r, V[t][n]) : __builtin_amdgcn_sad_u8(lw[n], r, V[t][n]);
+                else V[t][n] -= G::HI16 ? __builtin_amdgcn_sad_hi_u8(lw[n], r, 0u) : __builtin_amdgcn_sad_u8(lw[n], r, 0u);
+            }
+    }
     // ---- E: leftover bytes, packed here; two column offsets per register (a = 2p low half, 2p+1 high half) ----
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -271,8 +284,8 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
     };
 
     // ---- compute role ----
-    const int kgl = G::SWAPNET ? lane >> 4 : lane & 3;        // slot within the wave's four (group, class) combinations
-    const int sl = G::SWAPNET ? lane & 15 : lane >> 2;        // strip within the block
+    const int kgl = strip_lane_kgl(G::LANES, lane);         // slot within the wave's four (group, class) combinations
+    const int sl = strip_lane_strip(G::LANES, lane);        // strip within the block
     const int cq = 4 * wave + kgl;                            // (class, group) combination of this lane
     const int g = cq % NG, c = cq / NG;                       // disparity group (16 k each) and byte-alignment class
     const int kb = 16 * g + c;                                // k_t = kb + 4t
@@ -280,23 +293,27 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
     const int xs = xv - fr * p.Wp;
     const bool active = (fr < nf) && (xs < ocols) && (kb < p.D) && (kb <= xs + 15);
     const bool diag = active && (kb + 12 > xs);
-    const bool mask_d = G::POISON == 0 && __any(active && (kb + 12 >= p.D));   // see SG::POISON
+    const bool mask_d = !G::POISON_ANY && __any(active && (kb + 12 >= p.D));   // see SG::POISON, SG::KPOISON
     const bool any_diag = G::EPOISON == 0 && __any(diag);     // see SG::EPOISON
-    const EmitCtx ec = {kb, c, diag, {false, kb + 4 >= p.D, kb + 8 >= p.D, kb + 12 >= p.D}};
+    const EmitCtx ec = strip_emit_ctx<WIN>(kb, c, diag, p.D);
     const bool wave_active = __any(active);
     const bool wave_full = __all(active);
     const int sb = sl - g + NG;                               // R slot of (strip, group); reads start one slot lower
     const uint32_t *tL = rows + 4 * sl;
     const uint32_t *tR = rows + O::OFF_RP + c * O::SRP + 4 * (sb - 1);
 
-    uint32_t V[4][NV], E[4][4][2];
+    uint32_t V[G::VT][NV], E[4][4][2];
+    if constexpr (G::PKV) {
+        strip_init_sums_pk<WIN>(V, E);
+    } else {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const uint32_t v0 = (G::HI16 ? (uint32_t)(kb + 4 * t) : 0u) + (kb + 4 * t >= p.D ? (G::HI16 ? G::POISON << 16 : G::POISON) : 0u);
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t v0 = (G::HI16 ? (uint32_t)(kb + 4 * t) : 0u) + (kb + 4 * t >= p.D ? (G::HI16 ? G::POISON << 16 : G::POISON) : 0u);
 #pragma unroll
-        for (int n = 0; n < NV; ++n) V[t][n] = v0;
+            for (int n = 0; n < NV; ++n) V[t][n] = v0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { E[t][i][0] = 0; E[t][i][1] = 0; }
+            for (int i = 0; i < 4; ++i) { E[t][i][0] = 0; E[t][i][1] = 0; }
+        }
     }
     if constexpr (G::EPOISON != 0) {
         // diagonal lanes (xs == 16 g): slot (t, quad i, column offset a) never competes iff 4 (i - t) + a < c; slots with k >= D

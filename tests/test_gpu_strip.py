@@ -312,7 +312,7 @@ def test_half_height_blocks_at_the_end_of_the_launch(tail, monkeypatch):
                 assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), (tail, ty, H, W, win, D, i)
 
 
-@pytest.mark.parametrize("win", [5, 6, 7, 9, 11, 8, 13, 16, 17, 25])
+@pytest.mark.parametrize("win", [5, 6, 7, 9, 11, 8, 13, 16, 17, 18, 19, 20, 21, 22, 25])
 def test_largest_costs_with_poisoned_sums(win):
     """All-255 against all-0 (every absolute difference 255: the largest cost a window can have) and the reverse, checkerboards of
     the two, at D = 30 / 64 / 100: the poisoned sums of never-competing slots (k >= D, k > column) must stay above every real
@@ -322,8 +322,25 @@ def test_largest_costs_with_poisoned_sums(win):
     zero = np.zeros((H, W), np.uint8)
     yy, xx = np.mgrid[0:H, 0:W]
     chk = np.where((xx // 3 + yy) & 1, 255, 0).astype(np.uint8)
-    for D in (30, 64, 100):
+    for D in (30, 64, 100, 200, 256):
         for L, R in ((big, zero), (zero, big), (chk, 255 - chk), (big, chk)):
             exp = oracle.literal(L, R, win, D, oracle.RAW_LOC)
             got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC).cpu().numpy()
+            assert np.array_equal(got, exp), (win, D, np.argwhere(got != exp)[:4])
+
+
+@pytest.mark.parametrize("win", [17, 18, 19, 20, 21])
+def test_packed_word_sums_of_windows_17_to_21(win, form):
+    """Windows of 17-21 columns keep two disparities' whole-word sums in one register as 16-bit halves (SG::PKV): a word sum
+    reaches 4*255*win and a 3-word partial sum 64260 of 65535 -- all-255 against all-0 drives every half to its maximum, in
+    both kernel forms, with k >= D slots (poison through the key's k term) and the left border in the same frame."""
+    H, W = win + 7, 560
+    big = np.full((H, W), 255, np.uint8)
+    zero = np.zeros((H, W), np.uint8)
+    g = np.random.default_rng(win)
+    rnd = g.integers(0, 256, (H, W), dtype=np.uint8)
+    for D in (20, 50, 64, 90, 128, 250):
+        for L, R in ((big, zero), (zero, big), (rnd, np.roll(rnd, -33, axis=1)), (rnd, 255 - rnd)):
+            exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
+            got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP).cpu().numpy()
             assert np.array_equal(got, exp), (win, D, np.argwhere(got != exp)[:4])

@@ -19,9 +19,13 @@ Prints ONE JSON line on rank 0:
                         launch / the matcher kernel's average duration (HIP events on the launch stream); peak = the
                         measured issue rate of the instruction class the kernel is made of; the full-rate class and the
                         HBM roof (3*W*H bytes per frame, PMC traffic) are stated beside it
-  latency / frames_1080p_d128   one-frame call latency and the 1080p D=128 frame rate the metric names (N = 1 only)
+  latency / frames_* / cfg4_* / cfg5_*   one-frame call latency and one leg per other BASELINE configuration (N = 1 only), each with
+                        its kernel, kernel_ms, VALU fraction and a comparison of its output with the oracle
   cpu_baseline / cpu_baseline_1core   the CPU port of the reference loop on this box's host cores (N = 1 only)
-  verified_bit_exact    every pair of the last step compared with the CPU oracle, outside the timed region
+  verified_bit_exact    the last step compared with the CPU oracle, outside the timed region: every pair at N = 1; at N > 1 rank 0
+                        checks its own pairs (batch) or the gathered map against oracle.box of the whole frame (bands)
+  ranks                 N > 1: per-rank time of the timed region (min / max), and for --split bands the band compute and the
+                        gather timed separately after the timed region
 Inputs come from opencv_amd.synth; oracle/ is touched only after the timed region (verification + CPU baselines).
 """
 import argparse
@@ -200,10 +204,45 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     nl, matcher_ms, prep_ms = ctx.profile_end()
+    ranks_info = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        cdev = dev if backend == "nccl" else "cpu"
+        mine = torch.tensor([dt, matcher_ms / max(nl, 1)], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        dts = [float(a[0].item()) for a in allr]
+        kms = [float(a[1].item()) for a in allr]
+        dt = max(dts)                                      # the contract's time: the slowest rank
+        ranks_info = {"ms_per_step_min": round(min(dts) / args.steps * 1e3, 4), "ms_per_step_max": round(max(dts) / args.steps * 1e3, 4),
+                      "kernel_ms_min": round(min(kms), 4), "kernel_ms_max": round(max(kms), 4)}
+        if bands:
+            # compute and exchange separately (after the timed region): the band into this rank's slot, then the gather alone
+            per_rows = -(-H // world)
+            sendb = torch.zeros((per_rows, W), dtype=torch.uint8, device=dev)
+            fullb = torch.empty((world * per_rows, W), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize(); dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                if r1 > r0:
+                    compute_band(dLb, dRb, H, r0, r1 - r0, win, D, args.flags, sendb[: r1 - r0])
+            torch.cuda.synchronize()
+            tc = (time.perf_counter() - t1) / args.steps
+            dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(fullb, sendb)
+                else:
+                    hs = sendb.cpu(); ho = [torch.empty_like(hs) for _ in range(world)]
+                    dist.all_gather(ho, hs)
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - t1) / args.steps
+            tt = torch.tensor([tc, tg], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ranks_info["band_compute_ms_max"] = round(float(tt[0].item()) * 1e3, 4)
+            ranks_info["gather_ms_max"] = round(float(tt[1].item()) * 1e3, 4)
+            ranks_info["gather_note"] = "all_gather_into_tensor of %d x %d u8 rows per rank, timed alone" % (per_rows, W) if backend == "nccl" \
+                else "rehearsal backend %s: pieces through host memory" % backend
 
     evals_step = W * H * D * pairs                     # per GPU per step (metric counts full W*H*D)
     if bands:
@@ -216,15 +255,20 @@ def main():
     hbm_achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     valu_ops = float(OPS_PER_EVAL) * W * H * D * pairs * frac_rows
     valu_achieved = valu_ops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "bench_traffic.json")) as f:
-            tj = json.load(f)
-        ent = tj.get("%s|%s|pairs=%d" % (args.workload, ctx.last_kernel(), pairs))
-        if ent and not bands:
-            traffic = ent["hbm_bytes_per_launch"]
-    except (OSError, ValueError):
-        pass
+    # HBM traffic of the kernel that just ran: PMC passes cannot run inside this process, so the figure comes from the committed
+    # rocprofv3 summaries, keyed by (workload, kernel, pairs per launch).  A default-size run whose key is missing means the
+    # kernel changed without a new PMC pass: say so instead of quoting nothing (or somebody else's bytes).
+    traffic, traffic_src = None, None
+    with open(os.path.join(ROOT, "bench_traffic.json")) as f:
+        tj = json.load(f)
+    tkey = "%s|%s|pairs=%d" % (args.workload, ctx.last_kernel(), pairs)
+    ent = tj.get(tkey)
+    if not bands:
+        if ent:
+            traffic, traffic_src = ent["hbm_bytes_per_launch"], ent["source"]
+        elif args.pairs == 0 and args.flags == 0 and not os.environ.get("SADBM_BENCH_ALLOW_NO_TRAFFIC"):
+            raise SystemExit("bench: bench_traffic.json has no entry '%s' -- the kernel or batch size changed; run tools/prof.sh on this "
+                             "workload and add FETCH_SIZE / WRITE_SIZE of the new kernel (or set SADBM_BENCH_ALLOW_NO_TRAFFIC=1)" % tkey)
     line = {
         "metric": "Gdisp-evals/sec (WxHxD/s)", "value": round(value, 3), "unit": "Gdisp-evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -242,12 +286,32 @@ def main():
                      "peak_note": "39.3 T = measured issue rate of the 4-cycle VALU class the matcher consists of (v_sad_u8, v_perm_b32, "
                                   "v_min3_u32, v_pk_*: 4.2 cycles per wave64 and SIMD); 2-cycle class (v_add_u32 ...) 78.6 T",
                      "peak_full_rate": VALU_PEAK_FULL_RATE, "frac_full_rate": round(valu_achieved / VALU_PEAK_FULL_RATE, 4),
-                     "traffic_note": "traffic = HBM bytes per launch from the PMC passes (bench_traffic.json); algorithmic bytes below"},
+                     "traffic_note": "traffic = HBM bytes per launch from the PMC passes (bench_traffic.json); algorithmic bytes below",
+                     "traffic_source": traffic_src},
         # the secondary roof north_star asks for: HBM, algorithmic bytes 3*W*H per frame -- ~1 % of peak, by construction
         "hbm": {"bound": "hbm", "achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes": alg_bytes, "traffic": traffic},
         "verified_bit_exact": None,
     }
+    if ranks_info:
+        line["ranks"] = ranks_info
+    if rank == 0 and world > 1 and not args.no_verify:
+        # N > 1 lines verify themselves: rank 0 checks its own last step (batch: its pairs, at most 8 of them so that the other
+        # ranks do not wait long; bands: the gathered map against the single-call result of the whole frame, SAD.cpp:34-59)
+        import oracle
+        t0 = time.perf_counter()
+        if bands:
+            okv = sha(full[0].cpu().numpy()) == sha(oracle.box(Ls[0], Rs[0], win, D))
+            nchk = 1
+        else:
+            nchk = min(pairs, 8)
+            idx = [pairs - 1 - i for i in range(nchk)]
+            okv = all(sha(dO[i].cpu().numpy()) == sha(oracle.box(Ls[i], Rs[i], win, D)) for i in idx)
+        line["verified_bit_exact"] = bool(okv)
+        line["verified"] = ("rank 0: the gathered map equals oracle.box of the whole frame (sha256), %.1f s" if bands else
+                            "rank 0: the last %d of its %d frames of the last step equal oracle.box (sha256), %%.1f s" % (nchk, pairs)) % (time.perf_counter() - t0)
+        if not okv:
+            raise SystemExit("bench: rank 0's output differs from the oracle -- refusing to report a wrong kernel")
     if rank == 0 and world == 1 and not args.no_cpu:
         import oracle
         # (1) every pair of the last step against the sliding-sum oracle, whole frames, outside the timed region
@@ -292,10 +356,11 @@ def main():
             line["latency"] = {"frames": 1, "call_to_sync_ms": round(lat_ms, 4), "matcher_kernel_ms": round(m1 / max(n1, 1), 4),
                                "prep_kernel_ms": round(p1 / max(n1, 1), 4),
                                "value": round(W * H * D / (lat_ms * 1e-3) / 1e9, 1), "unit": "Gdisp-evals/s"}
-            # other workloads the metric names or the reference defaults to (SAD.cpp:9,11: winSize 7, DSR 30), 10 steps each, the last
-            # frame of the last step compared with the oracle
-            for key, wl, n2 in (("frames_1080p_d128", "cfg2b_1080p_w9_d128", 64), ("frames_1080p_d64", "cfg2_1080p_w9_d64", 64),
-                                ("frames_1080p_w7_d30", "cfg2c_1080p_w7_d30", 64), ("frames_384x288_w7_d30", "cfg1_tsukuba_size_w7_d30", 256)):
+            # the other BASELINE configurations and the reference's own parameters (SAD.cpp:9,11: winSize 7, DSR 30), 10 steps each:
+            # kernel, kernel time (HIP events), its VALU fraction, and frames of the last step compared with the oracle
+            for key, wl, n2, nver in (("frames_1080p_d128", "cfg2b_1080p_w9_d128", 64, 1), ("frames_1080p_d64", "cfg2_1080p_w9_d64", 64, 1),
+                                      ("frames_1080p_w7_d30", "cfg2c_1080p_w7_d30", 64, 1), ("frames_384x288_w7_d30", "cfg1_tsukuba_size_w7_d30", 256, 4),
+                                      ("cfg4_8k_w21_d256", "cfg4_8k_w21_d256", 4, 1), ("cfg5_kitti_w7_d128", "cfg5_kitti_w7_d128", 512, 16)):
                 if wl == args.workload:
                     continue
                 w2, h2, win2, d2, seed2, bg2, fg2, _n = WORKLOADS[wl]
@@ -306,18 +371,51 @@ def main():
                 for _ in range(3):
                     oa.compute_batch_device(l2, r2, win2, d2, 0, out=o2, ctx=ctx)
                 torch.cuda.synchronize()
+                ctx.profile_begin(10)
                 t0 = time.perf_counter()
                 for _ in range(10):
                     oa.compute_batch_device(l2, r2, win2, d2, 0, out=o2, ctx=ctx)
                 torch.cuda.synchronize()
                 dt2 = time.perf_counter() - t0
-                ok2 = sha(o2[n2 - 1].cpu().numpy()) == sha(oracle.box(fr[-1][0], fr[-1][1], win2, d2))
+                n3, m3, p3 = ctx.profile_end()
+                km = m3 / max(n3, 1)
+                chk = [n2 - 1 - (i * (n2 // nver)) for i in range(nver)]
+                ok2 = all(sha(o2[i].cpu().numpy()) == sha(oracle.box(fr[i][0], fr[i][1], win2, d2)) for i in chk)
                 line[key] = {"frames_per_s": round(n2 * 10 / dt2, 1), "value": round(w2 * h2 * d2 * n2 * 10 / dt2 / 1e9, 1),
                              "unit": "Gdisp-evals/s", "workload": "%dx%d, %dx%d, D=%d, %d frames per step, 10 steps" % (w2, h2, win2, win2, d2, n2),
-                             "kernel": ctx.last_kernel(), "last_frame_equals_oracle": ok2}
+                             "kernel": ctx.last_kernel(), "kernel_ms": round(km, 4), "prep_ms": round(p3 / max(n3, 1), 4),
+                             "valu_frac": round(OPS_PER_EVAL * w2 * h2 * d2 * n2 / (km * 1e-3) / 1e12 / VALU_PEAK_SAD_CLASS, 4) if km > 0 else None,
+                             "frames_checked": len(chk), "last_frame_equals_oracle": ok2}
                 del l2, r2, o2
                 if not ok2:
                     raise SystemExit("bench: %s output differs from the oracle" % wl)
+                if wl == "cfg4_8k_w21_d256":
+                    # the same frame through the row-band path of the N-GPU split (world 1: one band, no exchange partner)
+                    lf, rf = torch.from_numpy(fr[-1][0]).to(dev), torch.from_numpy(fr[-1][1]).to(dev)
+
+                    def cb(lbt, rbt, frame_rows, row0, rows_out, w, d, flags, out):
+                        return oa.compute_band_device(lbt, rbt, frame_rows, row0, rows_out, w, d, flags, out=out, ctx=ctx)
+                    for _ in range(2):
+                        fb = oa.disparity_row_bands(lf, rf, h2, win2, d2, 0, 1, compute_band=cb)
+                    torch.cuda.synchronize()
+                    ctx.profile_begin(10)
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        fb = oa.disparity_row_bands(lf, rf, h2, win2, d2, 0, 1, compute_band=cb)
+                    torch.cuda.synchronize()
+                    dt3 = time.perf_counter() - t0
+                    n4, m4, p4 = ctx.profile_end()
+                    km4 = m4 / max(n4, 1)
+                    ok3 = sha(fb.cpu().numpy()) == sha(oracle.box(fr[-1][0], fr[-1][1], win2, d2))
+                    line["cfg4_bands_world1"] = {"frames_per_s": round(10 / dt3, 1), "value": round(w2 * h2 * d2 * 10 / dt3 / 1e9, 1), "unit": "Gdisp-evals/s",
+                                                 "workload": "one %dx%d frame through disparity_row_bands (world 1), %dx%d, D=%d, 10 steps" % (w2, h2, win2, win2, d2),
+                                                 "kernel": ctx.last_kernel(), "kernel_ms": round(km4, 4), "prep_ms": round(p4 / max(n4, 1), 4),
+                                                 "valu_frac": round(OPS_PER_EVAL * w2 * h2 * d2 / (km4 * 1e-3) / 1e12 / VALU_PEAK_SAD_CLASS, 4) if km4 > 0 else None,
+                                                 "last_frame_equals_oracle": ok3}
+                    del lf, rf, fb
+                    if not ok3:
+                        raise SystemExit("bench: cfg4 row-band output differs from the oracle")
+                del fr
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

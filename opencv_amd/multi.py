@@ -58,9 +58,16 @@ def disparity_row_bands(left_band, right_band, frame_rows, win, max_disp, rank, 
         full = torch.empty((world * per, cols), dtype=torch.uint8, device=left_band.device)
         dist.all_gather_into_tensor(full, send, group=group)
         return full[:frame_rows]
-    # overlap needs a backend whose collectives run beside the compute stream (RCCL).  Any other backend with device
-    # tensors (gloo rehearsals on a GPU box) exchanges each piece through host memory and waits for it at once: gloo's
-    # own device-tensor path hung on some piece sizes (tools/gloo_bands_check.py).
+    # Ordering under RCCL: compute_band launches on torch's CURRENT stream (stereo.py passes torch.cuda.current_stream()); an
+    # async collective first makes RCCL's stream wait for an event recorded on the current stream at the call, so a piece is
+    # gathered after the kernels that wrote it; the next compute_band writes OTHER rows of `send`; work.wait() at the end makes
+    # the current stream wait for every gather.  Nothing depends on timing.  (The piece aliases outs[rank]: the gather writes
+    # a rank's own rows onto themselves.)
+    # Any other backend with device tensors (gloo rehearsals on a one-GPU box) exchanges each piece through host memory and
+    # waits for it at once.  Handing gloo the DEVICE tensors hung in round 2 (two ranks sharing GPU 0, 540 x 7680 pieces of
+    # the 8K frame); tools/gloo_piece_diag.py reproduced it once with stack dumps (profiles/r03_gloo_device_tensor_hang.txt):
+    # both ranks sit inside the third dist.all_gather(...) CALL -- not in wait() -- with each piece waited for before the
+    # next is issued and with piece.clone() / freshly allocated outputs, so neither the aliasing nor the async use causes it.
     backend = dist.get_backend(group)
     overlap = backend == "nccl" or not left_band.is_cuda
     via_host = left_band.is_cuda and backend != "nccl"

@@ -42,5 +42,22 @@ def test_gpus_2_spawns_two_ranks_and_refuses_a_mismatching_world():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    # an N > 1 line verifies itself (rank 0's pairs of the last step against the oracle) and carries the per-rank times
+    assert d["verified_bit_exact"] is True, d.get("verified")
+    assert d["ranks"]["ms_per_step_min"] <= d["ranks"]["ms_per_step_max"] and abs(d["ranks"]["ms_per_step_max"] - d["ms_per_step"]) < 1e-3
+    assert "cpu_baseline" not in d                                    # N = 1 only
     r, lines = run_bench(["--gpus", "2", "--no-cpu"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and not lines
+
+
+@pytest.mark.parametrize("sub_bands", ["1", "3"])
+def test_gpus_2_row_bands_line_is_verified_against_the_whole_frame(sub_bands):
+    """--split bands at N = 2 (two gloo ranks sharing the box's GPU): the gathered map of the last step equals oracle.box of the
+    whole frame -- the single-call result of SAD.cpp:34-59 -- and the line splits the step into band compute and gather."""
+    r, lines = run_bench(["--gpus", "2", "--split", "bands", "--sub-bands", sub_bands, "--workload", "cfg2_1080p_w9_d64", "--steps", "3", "--warmup", "1",
+                          "--no-cpu"], {"SADBM_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "row-bands2+allgather"
+    assert d["verified_bit_exact"] is True, d.get("verified")
+    assert d["ranks"]["band_compute_ms_max"] > 0 and d["ranks"]["gather_ms_max"] > 0

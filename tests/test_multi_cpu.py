@@ -111,12 +111,17 @@ def test_row_bands_all_gather_gloo_world2(H):
         assert np.array_equal(outs[r], exp), r
 
 
-@pytest.mark.parametrize("H,sub_bands,dst", [(41, 3, None), (40, 20, None), (37, 2, 1), (9, 4, 0)])
-def test_row_bands_pipelined_gather_and_gather_to_one_gloo_world2(H, sub_bands, dst):
-    """sub_bands > 1: pieces of the band are gathered asynchronously while the next one is computed; dst: only that rank
-    receives the map.  Bands shorter than the window and sub-bands of a single row included."""
+@pytest.mark.parametrize("H,sub_bands,dst,world", [(41, 3, None, 2), (40, 20, None, 2), (37, 2, 1, 2), (9, 4, 0, 2),
+                                                   (45, 4, None, 2),      # per = 23: pieces of 6, 6, 6, 5 rows, rank 1's band one row short
+                                                   (47, 5, None, 3),      # three ranks, per = 16: pieces 4, 4, 4, 4 (+ none), last band 15 rows
+                                                   (50, 7, 2, 3),         # seven outstanding pieces gathered to rank 2 only, last piece 2 rows
+                                                   (23, 6, None, 4)])     # four ranks, per = 6: six one-row pieces, the last band 5 rows
+def test_row_bands_pipelined_gather_and_gather_to_one_gloo_world2(H, sub_bands, dst, world):
+    """sub_bands > 1: pieces of the band are gathered asynchronously while the next one is computed (on CPU tensors every piece
+    stays outstanding until the end: 4-20 async works in flight); dst: only that rank receives the map.  Bands shorter than
+    the window, sub-bands of a single row, uneven last pieces and last bands, 2-4 ranks."""
     import torch.multiprocessing as mp
-    W, win, D, world = 52, 7, 16, 2
+    W, win, D = 52, 7, 16
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -150,8 +150,19 @@ int  sadbm_pipeline_wait(sadbm_pipeline *p, int64_t ticket, const uint8_t **resu
  *                             anchored top-left, SAD.cpp:39); every GPU computes its band into its slot of its own copy
  *                             of the full map and ONE all-gather of u8 bands (ncclAllGather, in place) leaves the full
  *                             rows x cols map on every GPU.  sub_bands > 1 splits each band further and gathers the
- *                             finished sub-band (grouped ncclBroadcast) while the next one is computed.  `out` (may be
- *                             NULL) receives the map from the first GPU; sadbm_multi_device_map gives each GPU's copy.
+ *                             finished sub-band (grouped ncclBroadcast) while the next one is computed.  Band i is
+ *                             staged (channel 0 gathered), uploaded and launched before band i+1 is staged.  `out` (may
+ *                             be NULL) receives every band from the GPU that computed it, over that GPU's own link;
+ *                             sadbm_multi_device_map gives each GPU's copy of the whole map.
+ *   sadbm_compute_multi_device the same for a frame that is ALREADY in the memory of one of the handle's GPUs (index
+ *                             src_index of `devices`; what SURVEY 8e calls "device-resident on one GPU"): that GPU reads
+ *                             its band in place, every other GPU pulls its band + halo rows with one peer copy per image on
+ *                             its own stream, then bands and gather as above.  dOut (may be NULL) = a rows x cols buffer on
+ *                             the source GPU that receives the map.  ASYNCHRONOUS like sadbm_compute_device: the inputs are
+ *                             read once `stream` (a stream of the source GPU, NULL = its default stream) reaches the call,
+ *                             and `stream` waits for every GPU before it goes on -- work queued on it afterwards sees dOut
+ *                             and every GPU's map; the host does not wait.  No reference counterpart (SAD.cpp:24,76: one
+ *                             caller, one thread, host Mats).
  *   sadbm_compute_multi_batch n_pairs independent pairs, pair n on GPU n % ngpu, no collective (batch data
  *                             parallelism).
  * Calls on one sadbm_multi are serialised (they share its staging buffers); none changes the caller's current device.
@@ -159,12 +170,19 @@ int  sadbm_pipeline_wait(sadbm_pipeline *p, int64_t ticket, const uint8_t **resu
  * interface without the collective; it also allows one device to be listed several times (rehearsal of the
  * partition on a single GPU). */
 #define SADBM_MULTI_COPY_GATHER 1u
+/* SADBM_MULTI_FORCE_PEER_COPY: sadbm_compute_multi_device treats every list entry other than src_index as a remote GPU even
+ * when it names the source device again, i.e. copies its band -- rehearsal of the scatter on a single GPU. */
+#define SADBM_MULTI_FORCE_PEER_COPY 2u
 typedef struct sadbm_multi sadbm_multi;
 int  sadbm_multi_create(int ngpu, const int *devices, uint32_t multi_flags, sadbm_multi **out);
 void sadbm_multi_destroy(sadbm_multi *m);
 int  sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_image *right, int win, int max_disp,
                          uint32_t flags, int sub_bands, sadbm_plane *out);
+int  sadbm_compute_multi_device(sadbm_multi *m, int src_index, const uint8_t *dL, int64_t pitchL, const uint8_t *dR, int64_t pitchR,
+                                int rows, int cols, int channels, int win, int max_disp, uint32_t flags, int sub_bands,
+                                uint8_t *dOut, int64_t out_pitch, void *stream);
 int  sadbm_multi_device_map(sadbm_multi *m, int index, const uint8_t **dmap, int64_t *pitch);
+int  sadbm_multi_device_id(const sadbm_multi *m, int index);     /* the HIP device behind list entry `index`, -1 if out of range */
 int  sadbm_compute_multi_batch(sadbm_multi *m, const sadbm_image *lefts, const sadbm_image *rights, int n_pairs, int win,
                                int max_disp, uint32_t flags, sadbm_plane *outs);
 /* Row partition used by sadbm_compute_multi (pure host arithmetic): band `index` of `parts` covers output rows

@@ -219,17 +219,17 @@ int sadbm_multi_create(int ngpu, const int *devices, uint32_t multi_flags, sadbm
         if (!rc && e == hipSuccess) e = hipEventCreateWithFlags(&g.ev_gather, hipEventDisableTiming);
         if (rc || e != hipSuccess) { if (!rc) rc = hip_err(e, "multi create"); sadbm_multi_destroy(m); return rc; }
     }
-    if (copy_gather) {
-        // peer access for the copies (ignored where it is already on or unsupported: hipMemcpyPeerAsync then stages)
-        for (int i = 0; i < ngpu; ++i)
-            for (int j = 0; j < ngpu; ++j)
-                if (devs[i] != devs[j]) {
-                    int can = 0;
-                    if (hipSetDevice(devs[i]) == hipSuccess && hipDeviceCanAccessPeer(&can, devs[i], devs[j]) == hipSuccess && can)
-                        (void)hipDeviceEnablePeerAccess(devs[j], 0);
-                }
-        (void)hipGetLastError();
-    } else {
+    // peer access for the copy gather and for the band scatter of sadbm_compute_multi_device (ignored where it is already on
+    // or unsupported: hipMemcpyPeerAsync then stages)
+    for (int i = 0; i < ngpu; ++i)
+        for (int j = 0; j < ngpu; ++j)
+            if (devs[i] != devs[j]) {
+                int can = 0;
+                if (hipSetDevice(devs[i]) == hipSuccess && hipDeviceCanAccessPeer(&can, devs[i], devs[j]) == hipSuccess && can)
+                    (void)hipDeviceEnablePeerAccess(devs[j], 0);
+            }
+    (void)hipGetLastError();
+    if (!copy_gather) {
         if (!load_rccl(m->rccl)) { sadbm_multi_destroy(m); return SADBM_E_RCCL; }
         std::vector<nccl_comm_t> comms(ngpu, nullptr);
         const int r = m->rccl.CommInitAll(comms.data(), ngpu, devs.data());
@@ -244,6 +244,135 @@ int sadbm_multi_create(int ngpu, const int *devices, uint32_t multi_flags, sadbm
     return SADBM_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Device rows [r0, i1) of GPU i's band (band + downward halo), as the matcher reads them.
+struct BandSrc { const uint8_t *l = nullptr, *r = nullptr; int64_t pl = 0, pr = 0; int ch = 1; };
+
+struct BandJob {
+    int rows, cols, win, D, n, per, sub_bands, sper;
+    uint32_t flags;
+    bool copy_gather;
+};
+
+// Sub-band s of GPU i: frame rows [r0 + s*sper, ...) computed straight into the band's slot of that GPU's map.
+int issue_sub_band(sadbm_multi *m, const BandJob &j, const BandSrc &b, int i, int s)
+{
+    Gpu &g = m->g[i];
+    int r0, r1, i1;
+    sadbm_band_plan(j.rows, j.n, j.win, i, &r0, &r1, &i1);
+    MHIP(hipSetDevice(g.device));
+    uint8_t *slot = g.dmap + (size_t)i * j.per * j.cols;
+    const int s0 = r0 + s * j.sper;                           // frame rows [s0, s1) of this sub-band
+    int s1 = s0 + j.sper; if (s1 > r1) s1 = r1;
+    if (s1 > s0) {
+        int si1 = s1 + j.win - 1; if (si1 > j.rows) si1 = j.rows;
+        const int rc = sadbm_compute_band_device(g.ctx, b.l + b.pl * (int64_t)(s0 - r0), b.pl, b.r + b.pr * (int64_t)(s0 - r0), b.pr, j.rows, s0,
+                                                 si1 - s0, s1 - s0, j.cols, b.ch, j.win, j.D, j.flags, slot + (size_t)(s0 - r0) * j.cols, j.cols, g.st);
+        if (rc) return rc;
+    }
+    MHIP(hipEventRecord(g.ev_band, g.st));
+    if (j.sub_bands > 1) MHIP(hipStreamWaitEvent(g.st_comm, g.ev_band, 0));
+    return SADBM_OK;
+}
+
+// Pipelined gather of sub-band s: every rank broadcasts its piece into the same place of everyone's map, on the comm
+// streams, while the compute streams go on with sub-band s+1.
+int gather_sub_band(sadbm_multi *m, const BandJob &j, int s)
+{
+    const int n = j.n;
+    const size_t off = (size_t)s * j.sper * j.cols;
+    int cnt_rows = j.sper; if (s * j.sper + cnt_rows > j.per) cnt_rows = j.per - s * j.sper;
+    if (cnt_rows <= 0) return SADBM_OK;                       // sub_bands * sper may overshoot the band
+    const size_t cnt = (size_t)cnt_rows * j.cols;
+    if (!j.copy_gather) {
+        MNCCL(m, m->rccl.GroupStart());
+        for (int root = 0; root < n; ++root)
+            for (int i = 0; i < n; ++i) {
+                Gpu &g = m->g[i];
+                uint8_t *p = g.dmap + (size_t)root * j.per * j.cols + off;
+                const int r = m->rccl.Broadcast(p, p, cnt, NCCL_UINT8, root, g.comm, g.st_comm);
+                if (r != 0) { (void)m->rccl.GroupEnd(); snprintf(g_multi_err, g_multi_err_size, "ncclBroadcast: %s", m->rccl.GetErrorString(r)); return SADBM_E_RCCL; }
+            }
+        MNCCL(m, m->rccl.GroupEnd());
+    } else {
+        for (int i = 0; i < n; ++i) {                         // destination i pulls every other band's piece
+            Gpu &g = m->g[i];
+            MHIP(hipSetDevice(g.device));
+            for (int k = 0; k < n; ++k) {
+                if (k == i) continue;
+                MHIP(hipStreamWaitEvent(g.st_comm, m->g[k].ev_band, 0));
+                const size_t o = (size_t)k * j.per * j.cols + off;
+                MHIP(hipMemcpyPeerAsync(g.dmap + o, g.device, m->g[k].dmap + o, m->g[k].device, cnt, g.st_comm));
+            }
+        }
+    }
+    return SADBM_OK;
+}
+
+// Everything after sub-band 0 of every GPU has been issued: the remaining sub-bands with their gathers, or the ONE in-place
+// all-gather of equal-sized u8 bands (un-pipelined form); on return every g.st is ordered after its GPU's complete map.
+int finish_bands(sadbm_multi *m, const BandJob &j, const BandSrc *src)
+{
+    const int n = j.n;
+    if (j.sub_bands > 1) {
+        int rc = gather_sub_band(m, j, 0);
+        if (rc) return rc;
+        for (int s = 1; s < j.sub_bands; ++s) {
+            for (int i = 0; i < n; ++i)
+                if ((rc = issue_sub_band(m, j, src[i], i, s))) return rc;
+            if ((rc = gather_sub_band(m, j, s))) return rc;
+        }
+        for (int i = 0; i < n; ++i) {                         // compute streams rejoin their gather streams
+            Gpu &g = m->g[i];
+            MHIP(hipSetDevice(g.device));
+            MHIP(hipEventRecord(g.ev_gather, g.st_comm));
+            MHIP(hipStreamWaitEvent(g.st, g.ev_gather, 0));
+        }
+        return SADBM_OK;
+    }
+    if (!j.copy_gather) {
+        MNCCL(m, m->rccl.GroupStart());
+        for (int i = 0; i < n; ++i) {
+            Gpu &g = m->g[i];
+            const int r = m->rccl.AllGather(g.dmap + (size_t)i * j.per * j.cols, g.dmap, (size_t)j.per * j.cols, NCCL_UINT8, g.comm, g.st);
+            if (r != 0) { (void)m->rccl.GroupEnd(); snprintf(g_multi_err, g_multi_err_size, "ncclAllGather: %s", m->rccl.GetErrorString(r)); return SADBM_E_RCCL; }
+        }
+        MNCCL(m, m->rccl.GroupEnd());
+    } else {
+        for (int i = 0; i < n; ++i) {
+            Gpu &g = m->g[i];
+            MHIP(hipSetDevice(g.device));
+            for (int k = 0; k < n; ++k) {
+                if (k == i) continue;
+                MHIP(hipStreamWaitEvent(g.st, m->g[k].ev_band, 0));
+                const size_t o = (size_t)k * j.per * j.cols;
+                MHIP(hipMemcpyPeerAsync(g.dmap + o, g.device, m->g[k].dmap + o, m->g[k].device, (size_t)j.per * j.cols, g.st));
+            }
+        }
+    }
+    return SADBM_OK;
+}
+
+BandJob make_job(const sadbm_multi *m, int rows, int cols, int win, int D, uint32_t flags, int sub_bands)
+{
+    BandJob j;
+    j.rows = rows; j.cols = cols; j.win = win; j.D = D; j.flags = flags; j.n = m->n;
+    j.copy_gather = (m->mflags & SADBM_MULTI_COPY_GATHER) != 0;
+    j.per = (rows + j.n - 1) / j.n;                           // rows per band; the last band(s) may be short or empty
+    if (sub_bands < 1) sub_bands = 1;
+    if (sub_bands > j.per) sub_bands = j.per;
+    j.sub_bands = sub_bands;
+    j.sper = (j.per + sub_bands - 1) / sub_bands;             // rows per sub-band (same on every GPU: equal counts)
+    return j;
+}
+
+}  // namespace
+
+extern "C" {
+
 int sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_image *right, int win, int max_disp,
                         uint32_t flags, int sub_bands, sadbm_plane *out)
 {
@@ -254,17 +383,16 @@ int sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_ima
     if (out && (out->rows != rows || out->cols != cols || out->step < cols)) return SADBM_E_SIZE;
     if (rows == 0 || cols == 0) return SADBM_OK;
     if (out && !out->data) return SADBM_E_NULL;
-    if (sub_bands < 1) sub_bands = 1;
     sadbm_detail::DeviceKeeper keep;
     std::lock_guard<std::mutex> guard(m->mu);
-    const bool copy_gather = (m->mflags & SADBM_MULTI_COPY_GATHER) != 0;
-    const int per = (rows + n - 1) / n;                       // rows per band; the last band(s) may be short or empty
-    if (sub_bands > per) sub_bands = per;
-    const int sper = (per + sub_bands - 1) / sub_bands;       // rows per sub-band (same on every GPU: equal counts)
+    const BandJob j = make_job(m, rows, cols, win, max_disp, flags, sub_bands);
+    const int per = j.per;
     const size_t pin = ((size_t)cols + 255) & ~(size_t)255;   // staged rows hold channel 0 only
     const size_t map_bytes = (size_t)n * per * cols;
+    std::vector<BandSrc> src(n);
 
-    // 1. per GPU: band + halo rows -> pinned -> device; zero the band slot's padding rows (bands past the frame's end)
+    // 1. GPU by GPU: band + halo rows -> pinned (channel 0 gathered on the way) -> device, and the first sub-band is launched
+    //    at once: GPU i uploads and computes while the host stages band i+1.  Nothing here blocks the host but the copies.
     for (int i = 0; i < n; ++i) {
         Gpu &g = m->g[i];
         int r0, r1, i1;
@@ -274,113 +402,122 @@ int sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_ima
         if ((rc = grow_dev(&g.dmap, &g.map_cap, map_bytes))) return rc;
         if ((rc = grow_host(&g.hin, &g.in_cap, 2 * pin * (size_t)(per + win)))) return rc;
         if ((rc = grow_dev(&g.din, &g.din_cap, 2 * pin * (size_t)(per + win)))) return rc;
+        if (out && (rc = grow_host(&g.hout, &g.out_cap, (size_t)per * cols))) return rc;
+        uint8_t *slot = g.dmap + (size_t)i * per * cols;
         if (rin > 0) {
+            // the previous call's upload from this pinned buffer has completed: every call ends with a stream synchronise
             copy_rows(g.hin, pin, left->data + (int64_t)r0 * left->step, left->step, (size_t)cols, rin, ch);
+            MHIP(hipMemcpyAsync(g.din, g.hin, pin * (size_t)rin, hipMemcpyHostToDevice, g.st));
             copy_rows(g.hin + pin * (size_t)rin, pin, right->data + (int64_t)r0 * right->step, right->step, (size_t)cols, rin, ch);
+            MHIP(hipMemcpyAsync(g.din + pin * (size_t)rin, g.hin + pin * (size_t)rin, pin * (size_t)rin, hipMemcpyHostToDevice, g.st));
         }
+        if (r1 - r0 < per) MHIP(hipMemsetAsync(slot + (size_t)(r1 - r0) * cols, 0, (size_t)(per - (r1 - r0)) * cols, g.st));
+        src[i].l = g.din; src[i].r = g.din + pin * (size_t)rin; src[i].pl = src[i].pr = (int64_t)pin; src[i].ch = 1;
+        if ((rc = issue_sub_band(m, j, src[i], i, 0))) return rc;
     }
-    // 2. H2D + band compute (sub-band by sub-band), each GPU on its own stream; nothing blocks the host
-    for (int s = 0; s < sub_bands; ++s) {
+    // 2. remaining sub-bands and the exchange step
+    if ((rc = finish_bands(m, j, src.data()))) return rc;
+
+    // 3. result: every GPU returns ITS band over its own PCIe link (the map itself stays on every GPU); then wait for all
+    if (out) {
         for (int i = 0; i < n; ++i) {
             Gpu &g = m->g[i];
             int r0, r1, i1;
             sadbm_band_plan(rows, n, win, i, &r0, &r1, &i1);
-            const int rin = i1 - r0;
+            if (r1 <= r0) continue;
             MHIP(hipSetDevice(g.device));
-            uint8_t *slot = g.dmap + (size_t)i * per * cols;
-            if (s == 0) {
-                if (rin > 0) MHIP(hipMemcpyAsync(g.din, g.hin, 2 * pin * (size_t)rin, hipMemcpyHostToDevice, g.st));
-                if (r1 - r0 < per) MHIP(hipMemsetAsync(slot + (size_t)(r1 - r0) * cols, 0, (size_t)(per - (r1 - r0)) * cols, g.st));
-            }
-            const int s0 = r0 + s * sper;                     // frame rows [s0, s1) of this sub-band
-            int s1 = s0 + sper; if (s1 > r1) s1 = r1;
-            if (s1 > s0) {
-                int si1 = s1 + win - 1; if (si1 > rows) si1 = rows;
-                const uint8_t *bl = g.din + pin * (size_t)(s0 - r0), *br = g.din + pin * (size_t)rin + pin * (size_t)(s0 - r0);
-                rc = sadbm_compute_band_device(g.ctx, bl, (int64_t)pin, br, (int64_t)pin, rows, s0, si1 - s0, s1 - s0, cols, 1, win,
-                                               max_disp, flags, slot + (size_t)(s0 - r0) * cols, cols, g.st);
-                if (rc) return rc;
-            }
-            MHIP(hipEventRecord(g.ev_band, g.st));
-            if (sub_bands > 1) MHIP(hipStreamWaitEvent(g.st_comm, g.ev_band, 0));
+            MHIP(hipMemcpyAsync(g.hout, g.dmap + (size_t)i * per * cols, (size_t)(r1 - r0) * cols, hipMemcpyDeviceToHost, g.st));
         }
-        if (sub_bands == 1) break;
-        // pipelined gather of sub-band s: every rank broadcasts its piece into the same place of everyone's map,
-        // on the comm streams, while the compute streams go on with sub-band s+1
-        const size_t off = (size_t)s * sper * cols;
-        int cnt_rows = sper; if (s * sper + cnt_rows > per) cnt_rows = per - s * sper;
-        if (cnt_rows <= 0) continue;                          // sub_bands * sper may overshoot the band
-        const size_t cnt = (size_t)cnt_rows * cols;
-        if (!copy_gather) {
-            MNCCL(m, m->rccl.GroupStart());
-            for (int root = 0; root < n; ++root)
-                for (int i = 0; i < n; ++i) {
-                    Gpu &g = m->g[i];
-                    uint8_t *p = g.dmap + (size_t)root * per * cols + off;
-                    const int r = m->rccl.Broadcast(p, p, cnt, NCCL_UINT8, root, g.comm, g.st_comm);
-                    if (r != 0) { (void)m->rccl.GroupEnd(); snprintf(g_multi_err, g_multi_err_size, "ncclBroadcast: %s", m->rccl.GetErrorString(r)); return SADBM_E_RCCL; }
-                }
-            MNCCL(m, m->rccl.GroupEnd());
-        } else {
-            for (int i = 0; i < n; ++i) {                     // destination i pulls every other band's piece
-                Gpu &g = m->g[i];
-                MHIP(hipSetDevice(g.device));
-                for (int j = 0; j < n; ++j) {
-                    if (j == i) continue;
-                    MHIP(hipStreamWaitEvent(g.st_comm, m->g[j].ev_band, 0));
-                    const size_t o = (size_t)j * per * cols + off;
-                    MHIP(hipMemcpyPeerAsync(g.dmap + o, g.device, m->g[j].dmap + o, m->g[j].device, cnt, g.st_comm));
-                }
-            }
-        }
-    }
-
-    // 3. the exchange step (un-pipelined form): ONE in-place all-gather of equal-sized u8 bands
-    if (sub_bands == 1) {
-        if (!copy_gather) {
-            MNCCL(m, m->rccl.GroupStart());
-            for (int i = 0; i < n; ++i) {
-                Gpu &g = m->g[i];
-                const int r = m->rccl.AllGather(g.dmap + (size_t)i * per * cols, g.dmap, (size_t)per * cols, NCCL_UINT8, g.comm, g.st);
-                if (r != 0) { (void)m->rccl.GroupEnd(); snprintf(g_multi_err, g_multi_err_size, "ncclAllGather: %s", m->rccl.GetErrorString(r)); return SADBM_E_RCCL; }
-            }
-            MNCCL(m, m->rccl.GroupEnd());
-        } else {
-            for (int i = 0; i < n; ++i) {
-                Gpu &g = m->g[i];
-                MHIP(hipSetDevice(g.device));
-                for (int j = 0; j < n; ++j) {
-                    if (j == i) continue;
-                    MHIP(hipStreamWaitEvent(g.st, m->g[j].ev_band, 0));
-                    const size_t o = (size_t)j * per * cols;
-                    MHIP(hipMemcpyPeerAsync(g.dmap + o, g.device, m->g[j].dmap + o, m->g[j].device, (size_t)per * cols, g.st));
-                }
-            }
-        }
-    } else {
-        for (int i = 0; i < n; ++i) {                         // compute streams rejoin their gather streams
-            Gpu &g = m->g[i];
-            MHIP(hipSetDevice(g.device));
-            MHIP(hipEventRecord(g.ev_gather, g.st_comm));
-            MHIP(hipStreamWaitEvent(g.st, g.ev_gather, 0));
-        }
-    }
-
-    // 4. result: the first GPU's copy of the map -> host (optional); then wait for every GPU
-    Gpu &g0 = m->g[0];
-    if (out) {
-        MHIP(hipSetDevice(g0.device));
-        if ((rc = grow_host(&g0.hout, &g0.out_cap, (size_t)rows * cols))) return rc;
-        MHIP(hipMemcpyAsync(g0.hout, g0.dmap, (size_t)rows * cols, hipMemcpyDeviceToHost, g0.st));
     }
     for (int i = 0; i < n; ++i) {
-        MHIP(hipSetDevice(m->g[i].device));
-        MHIP(hipStreamSynchronize(m->g[i].st));
+        Gpu &g = m->g[i];
+        MHIP(hipSetDevice(g.device));
+        MHIP(hipStreamSynchronize(g.st));
+        if (out) {
+            int r0, r1, i1;
+            sadbm_band_plan(rows, n, win, i, &r0, &r1, &i1);
+            if (r1 > r0) copy_rows(out->data + (int64_t)r0 * out->step, (size_t)out->step, g.hout, cols, (size_t)cols, r1 - r0);
+        }
     }
-    if (out) copy_rows(out->data, (size_t)out->step, g0.hout, cols, (size_t)cols, rows);
     m->map_rows = rows; m->map_cols = cols;
     return SADBM_OK;
 }
+
+int sadbm_compute_multi_device(sadbm_multi *m, int src_index, const uint8_t *dL, int64_t pitchL, const uint8_t *dR, int64_t pitchR,
+                               int rows, int cols, int channels, int win, int max_disp, uint32_t flags, int sub_bands,
+                               uint8_t *dOut, int64_t out_pitch, void *stream)
+{
+    if (!m) return SADBM_E_NULL;
+    if (src_index < 0 || src_index >= m->n) return SADBM_E_PARAM;
+    if (rows < 0 || cols < 0) return SADBM_E_SIZE;
+    if (channels != 1 && channels != 3 && channels != 4) return SADBM_E_TYPE;
+    if (win < 1 || win > 255 || max_disp < 1 || max_disp > 256) return SADBM_E_PARAM;
+    if (rows == 0 || cols == 0) return SADBM_OK;
+    if (!dL || !dR) return SADBM_E_NULL;
+    const int64_t rowb = (int64_t)cols * channels;
+    if (pitchL < rowb || pitchR < rowb || (dOut && out_pitch < cols)) return SADBM_E_SIZE;
+    const int n = m->n;
+    sadbm_detail::DeviceKeeper keep;
+    std::lock_guard<std::mutex> guard(m->mu);
+    const BandJob j = make_job(m, rows, cols, win, max_disp, flags, sub_bands);
+    const int per = j.per;
+    const size_t prow = ((size_t)rowb + 255) & ~(size_t)255;  // pitch of the peer copies (all channels travel; prep takes channel 0)
+    const size_t map_bytes = (size_t)n * per * cols;
+    Gpu &gs = m->g[src_index];
+    hipStream_t cs = (hipStream_t)stream;
+    std::vector<BandSrc> src(n);
+    int rc;
+
+    // the inputs are ready when the caller's stream gets here
+    MHIP(hipSetDevice(gs.device));
+    MHIP(hipEventRecord(gs.ev_gather, cs));
+    for (int i = 0; i < n; ++i) {
+        Gpu &g = m->g[i];
+        int r0, r1, i1;
+        sadbm_band_plan(rows, n, win, i, &r0, &r1, &i1);
+        const int rin = i1 - r0;
+        MHIP(hipSetDevice(g.device));
+        MHIP(hipStreamWaitEvent(g.st, gs.ev_gather, 0));
+        if ((rc = grow_dev(&g.dmap, &g.map_cap, map_bytes))) return rc;
+        uint8_t *slot = g.dmap + (size_t)i * per * cols;
+        if (r1 - r0 < per) MHIP(hipMemsetAsync(slot + (size_t)(r1 - r0) * cols, 0, (size_t)(per - (r1 - r0)) * cols, g.st));
+        if (i == src_index || (g.device == gs.device && !(m->mflags & SADBM_MULTI_FORCE_PEER_COPY))) {
+            // the band lives on this GPU already: the matcher reads the caller's rows in place
+            src[i].l = dL + pitchL * (int64_t)r0; src[i].r = dR + pitchR * (int64_t)r0; src[i].pl = pitchL; src[i].pr = pitchR; src[i].ch = channels;
+        } else {
+            // band + halo rows cross xGMI once, pulled by the GPU that needs them, on its own stream
+            if ((rc = grow_dev(&g.din, &g.din_cap, 2 * prow * (size_t)(per + win)))) return rc;
+            if (rin > 0) {
+                const uint8_t *sl = dL + pitchL * (int64_t)r0, *sr = dR + pitchR * (int64_t)r0;
+                uint8_t *dl = g.din, *dr = g.din + prow * (size_t)rin;
+                if ((size_t)pitchL == prow) MHIP(hipMemcpyPeerAsync(dl, g.device, sl, gs.device, prow * (size_t)(rin - 1) + (size_t)rowb, g.st));
+                else MHIP(hipMemcpy2DAsync(dl, prow, sl, (size_t)pitchL, (size_t)rowb, (size_t)rin, hipMemcpyDeviceToDevice, g.st));
+                if ((size_t)pitchR == prow) MHIP(hipMemcpyPeerAsync(dr, g.device, sr, gs.device, prow * (size_t)(rin - 1) + (size_t)rowb, g.st));
+                else MHIP(hipMemcpy2DAsync(dr, prow, sr, (size_t)pitchR, (size_t)rowb, (size_t)rin, hipMemcpyDeviceToDevice, g.st));
+            }
+            src[i].l = g.din; src[i].r = g.din + prow * (size_t)rin; src[i].pl = src[i].pr = (int64_t)prow; src[i].ch = channels;
+        }
+        if ((rc = issue_sub_band(m, j, src[i], i, 0))) return rc;
+    }
+    if ((rc = finish_bands(m, j, src.data()))) return rc;
+    // the map -> the caller's buffer on the source GPU (optional), then the caller's stream waits for every GPU: work queued
+    // on it after this call sees the output, every GPU's map, and inputs nobody reads any more.  The host does not wait.
+    if (dOut) {
+        MHIP(hipSetDevice(gs.device));
+        MHIP(hipMemcpy2DAsync(dOut, (size_t)out_pitch, gs.dmap, (size_t)cols, (size_t)cols, (size_t)rows, hipMemcpyDeviceToDevice, gs.st));
+    }
+    for (int i = 0; i < n; ++i) {
+        Gpu &g = m->g[i];
+        MHIP(hipSetDevice(g.device));
+        MHIP(hipEventRecord(g.ev_gather, g.st));
+        MHIP(hipSetDevice(gs.device));
+        MHIP(hipStreamWaitEvent(cs, g.ev_gather, 0));
+    }
+    m->map_rows = rows; m->map_cols = cols;
+    return SADBM_OK;
+}
+
+int sadbm_multi_device_id(const sadbm_multi *m, int index) { return (m && index >= 0 && index < m->n) ? m->g[index].device : -1; }
 
 int sadbm_multi_device_map(sadbm_multi *m, int index, const uint8_t **dmap, int64_t *pitch)
 {

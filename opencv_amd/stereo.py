@@ -101,6 +101,8 @@ def load_library():
     L.sadbm_multi_destroy.restype = None
     L.sadbm_compute_multi.argtypes = [vp, ctypes.POINTER(_Image), ctypes.POINTER(_Image), i32, i32, u32, i32, ctypes.POINTER(_Plane)]
     L.sadbm_multi_device_map.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    L.sadbm_compute_multi_device.argtypes = [vp, i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, u32, i32, vp, i64, vp]
+    L.sadbm_multi_device_id.argtypes = [vp, i32]
     L.sadbm_compute_multi_batch.argtypes = [vp, ctypes.POINTER(_Image), ctypes.POINTER(_Image), i32, i32, i32, u32, ctypes.POINTER(_Plane)]
     L.sadbm_band_plan.argtypes = [i32, i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.sadbm_reload_env.restype = None
@@ -108,7 +110,7 @@ def load_library():
     L.sadbm_plan_describe.restype = i32
     L.sadbm_thread_release.restype = None
     for name in ("sadbm_compute_device_static", "sadbm_multi_create", "sadbm_compute_multi", "sadbm_multi_device_map",
-                 "sadbm_compute_multi_batch", "sadbm_band_plan"):
+                 "sadbm_compute_multi_batch", "sadbm_band_plan", "sadbm_compute_multi_device", "sadbm_multi_device_id"):
         getattr(L, name).restype = i32
     for name in ("sadbm_profile_begin", "sadbm_profile_end", "sadbm_create", "sadbm_get_disparity", "sadbm_get_disparity_ctx", "sadbm_compute_device",
                  "sadbm_compute_band_device", "sadbm_compute_batch_device"):
@@ -268,6 +270,28 @@ def _tensor_view(t):
     return t, t.data_ptr(), pitch, rows, cols, ch
 
 
+def _storage_range(t):
+    """[first, last) byte addresses a strided tensor can touch."""
+    if t.numel() == 0:
+        return (0, 0)
+    last = sum((n - 1) * st for n, st in zip(t.shape, t.stride()))
+    return (t.data_ptr(), t.data_ptr() + (last + 1) * t.element_size())
+
+
+def _check_out(out, rows, cols, *inputs):
+    """A caller-supplied output plane goes straight to the kernels: rows x cols uint8 on the inputs' device, unit column stride,
+    and not overlapping an input (the direct-read kernels read the inputs while they write the output)."""
+    import torch
+    if (out.dtype != torch.uint8 or tuple(out.shape) != (rows, cols) or out.device != inputs[0].device
+            or (cols > 1 and out.stride(1) != 1) or (rows > 1 and out.stride(0) < cols)):
+        raise SadbmError(-3, "out must be a rows x cols uint8 tensor on the inputs' device with unit column stride")
+    o0, o1 = _storage_range(out)
+    for t in inputs:
+        i0, i1 = _storage_range(t)
+        if o0 < i1 and i0 < o1:
+            raise SadbmError(-3, "out overlaps an input image")
+
+
 def _stream_ptr(device):
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
@@ -288,6 +312,8 @@ def compute_device(left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags
     ctx = ctx or _ctx_for(dev)
     if out is None:
         out = torch.empty((rows, cols), dtype=torch.uint8, device=left.device)
+    else:
+        _check_out(out, rows, cols, lt, rt)
     opitch = out.stride(0) if rows > 1 else max(cols, 1)
     with torch.cuda.device(dev):
         _check(L.sadbm_compute_device(ctx.handle, lp, lpitch, rp, rpitch, rows, cols, ch, int(winSize), int(DSR), int(flags),
@@ -309,6 +335,8 @@ def compute_device_static(left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR
     dev = left.device.index or 0
     if out is None:
         out = torch.empty((rows, cols), dtype=torch.uint8, device=left.device)
+    else:
+        _check_out(out, rows, cols, lt, rt)
     opitch = out.stride(0) if rows > 1 else max(cols, 1)
     with torch.cuda.device(dev):
         _check(L.sadbm_compute_device_static(dev, lp, lpitch, rp, rpitch, rows, cols, ch, int(winSize), int(DSR), int(flags),
@@ -331,6 +359,8 @@ def compute_band_device(left_band, right_band, frame_rows, row0, rows_out, winSi
     ctx = ctx or _ctx_for(dev)
     if out is None:
         out = torch.empty((rows_out, cols), dtype=torch.uint8, device=left_band.device)
+    else:
+        _check_out(out, int(rows_out), cols, lt, rt)
     opitch = out.stride(0) if rows_out > 1 else max(cols, 1)
     with torch.cuda.device(dev):
         _check(L.sadbm_compute_band_device(ctx.handle, lp, lpitch, rp, rpitch, int(frame_rows), int(row0), rows_in,
@@ -454,6 +484,7 @@ class Pipeline:
 
 
 MULTI_COPY_GATHER = 1
+MULTI_FORCE_PEER_COPY = 2
 
 
 def band_plan(rows, parts, win, index):
@@ -500,16 +531,48 @@ class Multi:
                                                   int(sub_bands), ctypes.byref(op)))
         return out
 
+    def device_id(self, index):
+        """The HIP device behind entry `index` of the handle's device list."""
+        return load_library().sadbm_multi_device_id(self._h, int(index))
+
     def device_map(self, index, rows, cols):
         """Copy (torch uint8 tensor on that GPU) of GPU `index`'s full map of the last frame."""
         import torch
         ptr, pitch = ctypes.c_void_p(), ctypes.c_int64()
         _check(load_library().sadbm_multi_device_map(self._h, int(index), ctypes.byref(ptr), ctypes.byref(pitch)))
+        dev = self.device_id(index)                             # the pointer lives on THAT GPU, whatever the current device is
 
         class _Raw:                                             # raw device pointer -> torch via the CUDA array interface
             __cuda_array_interface__ = {"shape": (rows, cols), "typestr": "|u1", "data": (ptr.value, False), "version": 2,
                                         "strides": (pitch.value, 1)}
-        return torch.as_tensor(_Raw(), device="cuda").clone()
+        with torch.cuda.device(dev):
+            torch.cuda.synchronize(dev)                         # the async device form may still be filling the map
+            return torch.as_tensor(_Raw(), device=torch.device("cuda", dev)).clone()
+
+    def compute_device(self, left, right, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags=0, sub_bands=1, src_index=None, out=None):
+        """sadbm_compute_multi_device: left/right are uint8 CUDA tensors (HxW or HxWxC) on one of the handle's GPUs; returns
+        the map as a tensor on that GPU (asynchronous on its current stream); every GPU keeps a copy (device_map)."""
+        import torch
+        L = load_library()
+        lt, lp, lpitch, rows, cols, ch = _tensor_view(left)
+        rt, rp, rpitch, rrows, rcols, rch = _tensor_view(right)
+        if rch != ch:
+            raise SadbmError(-2, L.sadbm_strerror(-2).decode())
+        if rrows < rows or rcols < cols:
+            raise SadbmError(-3, L.sadbm_strerror(-3).decode())
+        dev = left.device.index or 0
+        if src_index is None:
+            src_index = next((i for i in range(self.ngpu) if self.device_id(i) == dev), -1)
+        if src_index < 0 or self.device_id(src_index) != dev:
+            raise SadbmError(-4, "the inputs are not on one of the handle's GPUs")
+        if out is None:
+            out = torch.empty((rows, cols), dtype=torch.uint8, device=left.device)
+        _check_out(out, rows, cols, left, right)
+        opitch = out.stride(0) if rows > 1 else max(cols, 1)
+        with torch.cuda.device(dev):
+            _check(L.sadbm_compute_multi_device(self._h, int(src_index), lp, lpitch, rp, rpitch, rows, cols, ch, int(winSize), int(DSR), int(flags),
+                                                int(sub_bands), out.data_ptr(), opitch, _stream_ptr(dev)))
+        return out
 
     def compute_batch(self, lefts, rights, winSize=DEFAULT_WIN_SIZE, DSR=DEFAULT_DSR, flags=0):
         n = len(lefts)

@@ -3,7 +3,8 @@
 // and run on the GPU box by tests/test_cpp_consumer.py.  It checks the entry points against each other and against the
 // known answers that need no oracle (K1 identical images, K2 constant images, K5 zero frame):
 //   sadbm::getDisparity(MatView)  ==  sadbm_compute_multi (1 GPU through RCCL)  ==  sadbm_compute_multi (3 "devices" on GPU 0,
-//   peer-copy gather, pipelined sub-bands)  ==  sadbm_compute_multi_batch  ==  the streaming pipeline.
+//   peer-copy gather, pipelined sub-bands)  ==  sadbm_compute_multi_device (the frame already in GPU memory, band scatter by
+//   peer copies)  ==  sadbm_compute_multi_batch  ==  the streaming pipeline.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +12,15 @@
 #include <vector>
 
 #include "sadbm.hpp"
+
+// the four HIP runtime calls a caller with device-resident frames makes itself (declared by hand: no HIP headers needed;
+// libamdhip64 is what libsadbm.so links anyway)
+extern "C" {
+int hipMalloc(void **ptr, size_t size);
+int hipFree(void *ptr);
+int hipMemcpy(void *dst, const void *src, size_t size, int kind);   // kind 1 = host to device, 2 = device to host
+int hipDeviceSynchronize(void);
+}
 
 static int fails = 0;
 #define CHECK(c, ...) do { if (!(c)) { ++fails; printf("FAIL line %d: ", __LINE__); printf(__VA_ARGS__); printf("\n"); } } while (0)
@@ -68,7 +78,7 @@ int main(int argc, char **argv)
             const int n = variant == 0 ? 1 : 3;
             const int devs[3] = {0, 0, 0};
             sadbm_multi *m = nullptr;
-            int rc = sadbm_multi_create(n, devs, variant == 0 ? 0u : SADBM_MULTI_COPY_GATHER, &m);
+            int rc = sadbm_multi_create(n, devs, variant == 0 ? 0u : variant == 1 ? SADBM_MULTI_COPY_GATHER : (SADBM_MULTI_COPY_GATHER | SADBM_MULTI_FORCE_PEER_COPY), &m);
             CHECK(rc == 0, "multi_create variant %d: %s (%s)", variant, sadbm_strerror(rc), sadbm_last_hip_error());
             if (rc) continue;
             sadbm::Image out(H, W, 1);
@@ -76,6 +86,21 @@ int main(int argc, char **argv)
             rc = sadbm_compute_multi(m, &li, &ri, win, D, SADBM_RAW_LOC, variant == 2 ? 5 : 1, &op);
             CHECK(rc == 0, "compute_multi variant %d: %s", variant, sadbm_strerror(rc));
             CHECK(out.pix == ref.pix, "compute_multi variant %d differs from getDisparity", variant);
+            // the same frame, already resident on GPU 0 (BGR, pitch = row bytes): entry 0 reads in place, the others pull their bands
+            {
+                const size_t fb = (size_t)H * W * 3;
+                void *dl = nullptr, *dr = nullptr, *dout = nullptr;
+                CHECK(hipMalloc(&dl, fb) == 0 && hipMalloc(&dr, fb) == 0 && hipMalloc(&dout, (size_t)H * W) == 0, "hipMalloc");
+                CHECK(hipMemcpy(dl, L.pix.data(), fb, 1) == 0 && hipMemcpy(dr, R.pix.data(), fb, 1) == 0, "hipMemcpy H2D");
+                rc = sadbm_compute_multi_device(m, n - 1, (const uint8_t *)dl, (int64_t)W * 3, (const uint8_t *)dr, (int64_t)W * 3, H, W, 3, win, D,
+                                                SADBM_RAW_LOC, variant == 2 ? 4 : 1, (uint8_t *)dout, W, nullptr);
+                CHECK(rc == 0, "compute_multi_device variant %d: %s (%s)", variant, sadbm_strerror(rc), sadbm_last_hip_error());
+                CHECK(hipDeviceSynchronize() == 0, "sync");       // the call is asynchronous
+                sadbm::Image dev_out(H, W, 1);
+                CHECK(hipMemcpy(dev_out.pix.data(), dout, (size_t)H * W, 2) == 0, "hipMemcpy D2H");
+                CHECK(dev_out.pix == ref.pix, "compute_multi_device variant %d differs from getDisparity", variant);
+                hipFree(dl); hipFree(dr); hipFree(dout);
+            }
             // batch: 5 pairs (the same pair five times, one with L and R swapped) dealt round-robin
             std::vector<sadbm_image> ls(5, li), rs(5, ri);
             ls[3] = ri; rs[3] = li;

@@ -46,6 +46,57 @@ def test_multi_copy_gather_virtual_devices(n, sub_bands):
     m.close()
 
 
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("sub_bands", [1, 5])
+def test_multi_device_resident_frame_rccl_one_rank(rccl_multi, sub_bands):
+    """sadbm_compute_multi_device with one RCCL rank: the frame is already on the GPU, the band is read in place."""
+    L, R = noise_pair(17, 131, 402, shift=9)
+    for win, D in ((15, 128), (7, 30), (21, 256)):
+        exp = oracle.box(L, R, win, D)
+        got = rccl_multi.compute_device(_dev(L), _dev(R), win, D, sub_bands=sub_bands)
+        assert np.array_equal(got.cpu().numpy(), exp), (win, D)
+        assert np.array_equal(rccl_multi.device_map(0, *L.shape).cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("n,src", [(2, 0), (3, 2), (5, 1), (8, 7)])
+@pytest.mark.parametrize("force_copy", [False, True])
+def test_multi_device_resident_frame_virtual_devices(n, src, force_copy):
+    """The device-resident form on 2-8 "devices" that are all GPU 0: the source entry reads its band in place, the others pull band
+    + halo rows with peer copies (MULTI_FORCE_PEER_COPY makes them do so although the device is the same), pitched ROI views,
+    BGR frames, H not divisible by n, bands shorter than the window, two calls in a row without a host wait in between."""
+    import torch
+    m = oa.Multi(n, devices=[0] * n, multi_flags=oa.MULTI_COPY_GATHER | (oa.MULTI_FORCE_PEER_COPY if force_copy else 0))
+    for (H, W, ch) in ((97, 150, 1), (11, 90, 1), (64, 257, 3)):
+        L, R = noise_pair(H + n, H, W, shift=4, ch=ch)
+        L2, R2 = noise_pair(H + n + 1, H, W, shift=7, ch=ch)
+        big = torch.zeros((H + 6, W + 10) + ((ch,) if ch > 1 else ()), dtype=torch.uint8, device="cuda")
+        big[3:3 + H, 5:5 + W] = _dev(L)                         # an ROI view: pitch > row bytes (2-D peer copies)
+        for win, D, sb in ((9, 40, 1), (15, 128, 3)):
+            p0 = lambda a: np.ascontiguousarray(a[..., 0]) if ch > 1 else a
+            got = m.compute_device(big[3:3 + H, 5:5 + W], _dev(R), win, D, sub_bands=sb, src_index=src)
+            got2 = m.compute_device(_dev(L2), _dev(R2), win, D, sub_bands=sb, src_index=src)     # queued behind the first call
+            assert np.array_equal(got.cpu().numpy(), oracle.box(p0(L), p0(R), win, D)), (n, src, H, W, ch, win, D)
+            exp2 = oracle.box(p0(L2), p0(R2), win, D)
+            assert np.array_equal(got2.cpu().numpy(), exp2), (n, src, H, W, ch, win, D, "second call")
+            for i in range(n):                                  # every "GPU" ends with the full map of the last call
+                assert np.array_equal(m.device_map(i, H, W).cpu().numpy(), exp2), i
+    # the host form on the same handle afterwards (shares the staging buffers and the streams)
+    L, R = noise_pair(5, 50, 120, shift=3)
+    assert np.array_equal(m.compute(L, R, 7, 30), oracle.box(L, R, 7, 30))
+    m.close()
+
+
+def test_multi_device_rejects_foreign_inputs_and_bad_index(rccl_multi):
+    L, R = noise_pair(1, 20, 40, shift=2)
+    with pytest.raises(oa.SadbmError) as e:
+        rccl_multi.compute_device(_dev(L), _dev(R), 7, 30, src_index=3)
+    assert e.value.code == -4
+
+
 @pytest.mark.parametrize("n", [1, 3])
 def test_multi_batch_round_robin(rccl_multi, n):
     m = rccl_multi if n == 1 else oa.Multi(n, devices=[0] * n, multi_flags=oa.MULTI_COPY_GATHER)

@@ -36,6 +36,16 @@ def test_oracles_under_asan_ubsan(asan_tools):
     assert "oracle selftest: ok" in r.stdout
 
 
+def test_host_row_copies_under_asan_ubsan(asan_tools):
+    """hostcopy.hpp (the SSSE3 / AVX2 channel-0 gather and the copy pool of the host API) on exact-size heap buffers: odd
+    widths, 3 / 4 channels, tails, pitched rows, pool-split copies, four calling threads."""
+    exe = os.path.join(ROOT, "opencv_amd", "csrc", "hostcopy_asan_selftest")
+    env = dict(ENV, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=99")     # the pool's detached workers never exit
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "hostcopy selftest: ok" in r.stdout
+
+
 def test_valid_files_convert_under_asan(asan_tools, tmp_path):
     for name in ("tsukuba_left.png", "tsukuba_left.ppm", "tsukuba_disp_w7_d30.pgm", "cat.bmp", "gaus_cat_low.png"):
         for ext in ("png", "bmp", "ppm"):

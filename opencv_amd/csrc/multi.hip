@@ -180,8 +180,8 @@ void sadbm_multi_destroy(sadbm_multi *m)
         if (g.din) (void)hipFree(g.din);
         if (g.dmap) (void)hipFree(g.dmap);
         sadbm_destroy(g.ctx);
-        if (g.st) (void)hipStreamDestroy(g.st);
-        if (g.st_comm) (void)hipStreamDestroy(g.st_comm);
+        sadbm_detail::stream_release(g.device, g.st);
+        sadbm_detail::stream_release(g.device, g.st_comm);
     }
     // the RCCL handle stays loaded (other users in the process may hold it)
     delete m;
@@ -213,8 +213,8 @@ int sadbm_multi_create(int ngpu, const int *devices, uint32_t multi_flags, sadbm
         g.device = devs[i];
         hipError_t e = hipSetDevice(g.device);
         int rc = e == hipSuccess ? sadbm_create(g.device, &g.ctx) : SADBM_E_HIP;
-        if (!rc) e = hipStreamCreateWithFlags(&g.st, hipStreamNonBlocking);
-        if (!rc && e == hipSuccess) e = hipStreamCreateWithFlags(&g.st_comm, hipStreamNonBlocking);
+        if (!rc) e = sadbm_detail::stream_acquire(g.device, &g.st);
+        if (!rc && e == hipSuccess) e = sadbm_detail::stream_acquire(g.device, &g.st_comm);
         if (!rc && e == hipSuccess) e = hipEventCreateWithFlags(&g.ev_band, hipEventDisableTiming);
         if (!rc && e == hipSuccess) e = hipEventCreateWithFlags(&g.ev_gather, hipEventDisableTiming);
         if (rc || e != hipSuccess) { if (!rc) rc = hip_err(e, "multi create"); sadbm_multi_destroy(m); return rc; }
@@ -391,6 +391,23 @@ int sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_ima
     const size_t map_bytes = (size_t)n * per * cols;
     std::vector<BandSrc> src(n);
 
+    // 0. every buffer of every GPU first, while nothing is in flight (an earlier sadbm_compute_multi_device on this handle may
+    //    still be: drain it): hipFree / hipHostFree wait for their own device only, and an allocation between GPU i's launch and
+    //    GPU i+1's staging would serialise exactly what step 1 overlaps
+    for (int i = 0; i < n; ++i) {
+        Gpu &g = m->g[i];
+        MHIP(hipSetDevice(g.device));
+        MHIP(hipStreamSynchronize(g.st));
+        MHIP(hipStreamSynchronize(g.st_comm));
+    }
+    for (int i = 0; i < n; ++i) {
+        Gpu &g = m->g[i];
+        MHIP(hipSetDevice(g.device));
+        if ((rc = grow_dev(&g.dmap, &g.map_cap, map_bytes))) return rc;
+        if ((rc = grow_host(&g.hin, &g.in_cap, 2 * pin * (size_t)(per + win)))) return rc;
+        if ((rc = grow_dev(&g.din, &g.din_cap, 2 * pin * (size_t)(per + win)))) return rc;
+        if (out && (rc = grow_host(&g.hout, &g.out_cap, (size_t)per * cols))) return rc;
+    }
     // 1. GPU by GPU: band + halo rows -> pinned (channel 0 gathered on the way) -> device, and the first sub-band is launched
     //    at once: GPU i uploads and computes while the host stages band i+1.  Nothing here blocks the host but the copies.
     for (int i = 0; i < n; ++i) {
@@ -399,10 +416,6 @@ int sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_ima
         sadbm_band_plan(rows, n, win, i, &r0, &r1, &i1);
         const int rin = i1 - r0;
         MHIP(hipSetDevice(g.device));
-        if ((rc = grow_dev(&g.dmap, &g.map_cap, map_bytes))) return rc;
-        if ((rc = grow_host(&g.hin, &g.in_cap, 2 * pin * (size_t)(per + win)))) return rc;
-        if ((rc = grow_dev(&g.din, &g.din_cap, 2 * pin * (size_t)(per + win)))) return rc;
-        if (out && (rc = grow_host(&g.hout, &g.out_cap, (size_t)per * cols))) return rc;
         uint8_t *slot = g.dmap + (size_t)i * per * cols;
         if (rin > 0) {
             // the previous call's upload from this pinned buffer has completed: every call ends with a stream synchronise
@@ -468,6 +481,27 @@ int sadbm_compute_multi_device(sadbm_multi *m, int src_index, const uint8_t *dL,
     std::vector<BandSrc> src(n);
     int rc;
 
+    // Buffers first.  This form is asynchronous: the previous call's work may still be in flight on every GPU, and a map or
+    // staging buffer that has to grow may still be read by ANOTHER GPU's peer copies (hipFree only waits for its own device):
+    // when anything grows, every stream of the handle is drained before the first buffer is released.
+    auto reads_in_place = [&](int i) { return i == src_index || (m->g[i].device == gs.device && !(m->mflags & SADBM_MULTI_FORCE_PEER_COPY)); };
+    const size_t din_bytes = 2 * prow * (size_t)(per + win);
+    bool grows = false;
+    for (int i = 0; i < n; ++i) grows = grows || m->g[i].map_cap < map_bytes || (!reads_in_place(i) && m->g[i].din_cap < din_bytes);
+    if (grows) {
+        for (int i = 0; i < n; ++i) {
+            Gpu &g = m->g[i];
+            MHIP(hipSetDevice(g.device));
+            MHIP(hipStreamSynchronize(g.st));
+            MHIP(hipStreamSynchronize(g.st_comm));
+        }
+        for (int i = 0; i < n; ++i) {
+            Gpu &g = m->g[i];
+            MHIP(hipSetDevice(g.device));
+            if ((rc = grow_dev(&g.dmap, &g.map_cap, map_bytes))) return rc;
+            if (!reads_in_place(i) && (rc = grow_dev(&g.din, &g.din_cap, din_bytes))) return rc;
+        }
+    }
     // the inputs are ready when the caller's stream gets here
     MHIP(hipSetDevice(gs.device));
     MHIP(hipEventRecord(gs.ev_gather, cs));
@@ -478,15 +512,13 @@ int sadbm_compute_multi_device(sadbm_multi *m, int src_index, const uint8_t *dL,
         const int rin = i1 - r0;
         MHIP(hipSetDevice(g.device));
         MHIP(hipStreamWaitEvent(g.st, gs.ev_gather, 0));
-        if ((rc = grow_dev(&g.dmap, &g.map_cap, map_bytes))) return rc;
         uint8_t *slot = g.dmap + (size_t)i * per * cols;
         if (r1 - r0 < per) MHIP(hipMemsetAsync(slot + (size_t)(r1 - r0) * cols, 0, (size_t)(per - (r1 - r0)) * cols, g.st));
-        if (i == src_index || (g.device == gs.device && !(m->mflags & SADBM_MULTI_FORCE_PEER_COPY))) {
+        if (reads_in_place(i)) {
             // the band lives on this GPU already: the matcher reads the caller's rows in place
             src[i].l = dL + pitchL * (int64_t)r0; src[i].r = dR + pitchR * (int64_t)r0; src[i].pl = pitchL; src[i].pr = pitchR; src[i].ch = channels;
         } else {
             // band + halo rows cross xGMI once, pulled by the GPU that needs them, on its own stream
-            if ((rc = grow_dev(&g.din, &g.din_cap, 2 * prow * (size_t)(per + win)))) return rc;
             if (rin > 0) {
                 const uint8_t *sl = dL + pitchL * (int64_t)r0, *sr = dR + pitchR * (int64_t)r0;
                 uint8_t *dl = g.din, *dr = g.din + prow * (size_t)rin;
@@ -547,7 +579,13 @@ int sadbm_compute_multi_batch(sadbm_multi *m, const sadbm_image *lefts, const sa
     sadbm_detail::DeviceKeeper keep;
     std::lock_guard<std::mutex> guard(m->mu);
     const size_t pin = ((size_t)cols + 255) & ~(size_t)255, pout = pin;   // staged rows hold channel 0 only
-    // pair p -> GPU p % n, slot p / n of that GPU's staging; one batched launch sequence per GPU, no collective
+    // buffers first, with the handle drained (see sadbm_compute_multi)
+    for (int i = 0; i < n; ++i) {
+        Gpu &g = m->g[i];
+        MHIP(hipSetDevice(g.device));
+        MHIP(hipStreamSynchronize(g.st));
+        MHIP(hipStreamSynchronize(g.st_comm));
+    }
     for (int i = 0; i < n; ++i) {
         Gpu &g = m->g[i];
         const int mine = (n_pairs - i + n - 1) / n;
@@ -559,6 +597,15 @@ int sadbm_compute_multi_batch(sadbm_multi *m, const sadbm_image *lefts, const sa
         if ((rc = grow_dev(&g.din, &g.din_cap, in_need))) return rc;
         if ((rc = grow_host(&g.hout, &g.out_cap, out_need))) return rc;
         if ((rc = grow_dev(&g.dmap, &g.map_cap, out_need))) return rc;
+    }
+    // pair p -> GPU p % n, slot p / n of that GPU's staging; one batched launch sequence per GPU, no collective
+    for (int i = 0; i < n; ++i) {
+        Gpu &g = m->g[i];
+        const int mine = (n_pairs - i + n - 1) / n;
+        if (mine <= 0) continue;
+        MHIP(hipSetDevice(g.device));
+        int rc;
+        const size_t in_need = 2 * pin * rows * (size_t)mine, out_need = pout * rows * (size_t)mine;
         uint8_t *hL = g.hin, *hR = g.hin + pin * rows * (size_t)mine;
         for (int k = 0; k < mine; ++k) {
             const int p = i + k * n;

@@ -862,6 +862,50 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     return SADBM_OK;
 }
 
+}  // namespace
+
+namespace sadbm_detail {
+namespace {
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::vector<hipStream_t>> idle;               // per device
+};
+// never destroyed: at process exit the HIP runtime may already be gone
+StreamPool &stream_pool() { static StreamPool *p = new StreamPool(); return *p; }
+constexpr size_t STREAM_POOL_MAX = 256;                        // idle streams kept per device; beyond that they are destroyed after all
+}  // namespace
+
+hipError_t stream_acquire(int device, hipStream_t *out)
+{
+    StreamPool &sp = stream_pool();
+    {
+        std::lock_guard<std::mutex> guard(sp.mu);
+        if (device >= 0 && (size_t)device < sp.idle.size() && !sp.idle[device].empty()) {
+            *out = sp.idle[device].back();
+            sp.idle[device].pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void stream_release(int device, hipStream_t s)
+{
+    if (!s) return;
+    StreamPool &sp = stream_pool();
+    {
+        std::lock_guard<std::mutex> guard(sp.mu);
+        if (device >= 0 && device < 1024) {
+            if ((size_t)device >= sp.idle.size()) sp.idle.resize((size_t)device + 1);
+            if (sp.idle[device].size() < STREAM_POOL_MAX) { sp.idle[device].push_back(s); return; }
+        }
+    }
+    (void)hipStreamDestroy(s);
+}
+}  // namespace sadbm_detail
+
+namespace {
+
 // The convenience call sadbm_get_disparity() keeps one context per host thread; it is released when the thread exits
 // (stream, device scratch, pinned staging -- about 25 MB per 4K pair).  Main-thread thread_locals are destroyed before
 // static-storage objects, i.e. while the HIP runtime is still alive.
@@ -914,9 +958,9 @@ int sadbm_create(int device, sadbm_ctx **out)
     sadbm_ctx *c = new (std::nothrow) sadbm_ctx();
     if (!c) return SADBM_E_ALLOC;
     c->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e = stream_acquire(device, &c->stream);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->xev, hipEventDisableTiming);
-    if (e != hipSuccess) { if (c->stream) (void)hipStreamDestroy(c->stream); delete c; return hip_fail(e, "hipStreamCreate"); }
+    if (e != hipSuccess) { stream_release(device, c->stream); delete c; return hip_fail(e, "hipStreamCreate"); }
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->cus = v; }
     *out = c;
     return SADBM_OK;
@@ -927,7 +971,7 @@ void sadbm_destroy(sadbm_ctx *c)
     if (!c) return;
     DeviceScope dscope(c->device);
     // the scratch may still be read by kernels the caller queued on its own stream: hipFree waits for the device
-    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); stream_release(c->device, c->stream); }
     if (c->planes && !c->planes_fixed) (void)hipFree(c->planes);
     if (c->stage_in) (void)hipFree(c->stage_in);
     if (c->stage_out) (void)hipFree(c->stage_out);
@@ -935,8 +979,8 @@ void sadbm_destroy(sadbm_ctx *c)
     if (c->pin_in) (void)hipHostFree(c->pin_in);
     if (c->pin_out) (void)hipHostFree(c->pin_out);
     if (c->xev) (void)hipEventDestroy(c->xev);
-    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-    if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); stream_release(c->device, c->stream2); }
+    if (c->stream3) { (void)hipStreamSynchronize(c->stream3); stream_release(c->device, c->stream3); }
     for (hipEvent_t e : c->chunk_ev) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 3 * c->ev_cap; ++i) (void)hipEventDestroy(c->ev[i]);
     delete[] c->ev;
@@ -1206,8 +1250,8 @@ int sadbm_get_disparity_ctx(sadbm_ctx *ctx, const sadbm_image *left, const sadbm
         int nch = (int)(in_bytes >> 21);                        // one chunk per 2 MB of input, 2 .. 8
         nch = nch < 2 ? 2 : nch > 8 ? 8 : nch;
         const int chunk = (rows + nch - 1) / nch;
-        if (!ctx->stream2) HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        if (!ctx->stream3) HIPCHK(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+        if (!ctx->stream2) HIPCHK(stream_acquire(ctx->device, &ctx->stream2));
+        if (!ctx->stream3) HIPCHK(stream_acquire(ctx->device, &ctx->stream3));
         hipStream_t up = ctx->stream3;                          // uploads run on their own stream: chunk j+1 travels while chunk j is matched
         for (int i = 0; i < 3 * 16; ++i)
             if (!ctx->chunk_ev[i]) HIPCHK(hipEventCreateWithFlags(&ctx->chunk_ev[i], hipEventDisableTiming));

@@ -103,5 +103,12 @@ struct DeviceKeeper {
     DeviceKeeper &operator=(const DeviceKeeper &) = delete;
 };
 
+// Streams of the library (contexts, multi-GPU handles) come from a per-device pool and go back to it instead of being destroyed
+// (sadbm.hip): hipStreamDestroy of a stream whose last operations were cross-stream waits and asynchronous host copies, right
+// after hipStreamSynchronize, crashed inside the runtime's hsa_signal_destroy on MI355X / ROCm 7.0 (profiles/r03b_stream_destroy_crash.txt);
+// a pooled stream is idle (the owner synchronises it before the release), non-blocking, and as good as a new one.
+hipError_t stream_acquire(int device, hipStream_t *out);    // `device` must be current
+void stream_release(int device, hipStream_t s);             // synchronised by the caller; `device` must be current
+
 }  // namespace sadbm_detail
 #endif

@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("SADBM_ABRT_TRACE") == "1":              # debugging aid: native backtrace on SIGABRT (tools/dbg/abrt_trace.c)
+        import ctypes
+        so = os.path.join(ROOT, "tools", "dbg", "libabrt_trace.so")
+        if os.path.exists(so):
+            ctypes.CDLL(so).abrt_trace_install()
 
 
 @pytest.fixture(scope="session")

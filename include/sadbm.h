@@ -31,7 +31,7 @@ extern "C" {
 #define SADBM_VERSION 200
 
 /* flags */
-#define SADBM_RAW_LOC        1u   /* write loc (0..max_disp-1) instead of (loc*16)&255; needs max_disp<=256 */
+#define SADBM_RAW_LOC        1u   /* write loc (0..max_disp-1) instead of (loc*16)&255; a byte, so it needs max_disp<=256 */
 #define SADBM_FORCE_GENERIC  2u   /* use the brute-force HIP kernel (any win); for cross-checks */
 #define SADBM_KERNEL_GLOBAL  4u   /* use the matcher variant that reads operands through L1 instead of LDS (A/B) */
 #define SADBM_KERNEL_STRIP   8u   /* force the strip matcher (16 columns x 4 disparities per thread; 4 <= win <= 25) */
@@ -44,7 +44,11 @@ extern "C" {
                                (the reference would throw inside cv::absdiff, SAD.cpp:17) */
 #define SADBM_E_SIZE   -3   /* right smaller than left (the reference would throw in Mat::operator()(Rect),
                                SAD.cpp:47), negative sizes, or a pitch smaller than a row */
-#define SADBM_E_PARAM  -4   /* win<1, max_disp<1, max_disp>256, win>255 */
+#define SADBM_E_PARAM  -4   /* win<1 or max_disp<1 (the reference would loop over nothing / throw); SADBM_RAW_LOC with
+                               max_disp>256 (loc does not fit the output byte); win>4096 on a frame larger than that.
+                               winSize and DSR are plain ints in the reference (SAD.cpp:9,11) and it accepts any value:
+                               so does this library, in the reference's encoding -- DSR>256 and windows of 256..4096
+                               columns run slower matchers */
 #define SADBM_E_HIP    -5   /* HIP runtime error (sadbm_last_hip_error() has the text) */
 #define SADBM_E_ALLOC  -6   /* device memory allocation failed */
 #define SADBM_E_BUSY   -7   /* pipeline slot still in flight (wait on its ticket first) / unknown ticket */

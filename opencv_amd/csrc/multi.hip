@@ -127,13 +127,14 @@ void copy_rows(uint8_t *dst, size_t dstep, const uint8_t *src, int64_t sstep, si
     sadbm_internal_copy_rows(dst, (int64_t)dstep, src, sstep, cols, rows, ch);
 }
 
-int check_pair(const sadbm_image *l, const sadbm_image *r, int win, int D)
+int check_pair(const sadbm_image *l, const sadbm_image *r, int win, int D, uint32_t flags)
 {
     if (!l || !r) return SADBM_E_NULL;
     if (l->rows < 0 || l->cols < 0) return SADBM_E_SIZE;
     if (l->channels != 1 && l->channels != 3 && l->channels != 4) return SADBM_E_TYPE;
     if (r->channels != l->channels) return SADBM_E_TYPE;                        // cv::absdiff would throw (SAD.cpp:17)
-    if (win < 1 || win > 255 || D < 1 || D > 256) return SADBM_E_PARAM;
+    if (win < 1 || D < 1 || ((flags & SADBM_RAW_LOC) && D > 256)) return SADBM_E_PARAM;   // as check_params of sadbm.hip
+    if (win > 4096 && l->rows > win && l->cols > win) return SADBM_E_PARAM;
     if (r->rows < l->rows || r->cols < l->cols) return SADBM_E_SIZE;            // Mat ROI would throw (SAD.cpp:47)
     if (l->rows == 0 || l->cols == 0) return SADBM_OK;
     if (!l->data || !r->data) return SADBM_E_NULL;
@@ -377,7 +378,7 @@ int sadbm_compute_multi(sadbm_multi *m, const sadbm_image *left, const sadbm_ima
                         uint32_t flags, int sub_bands, sadbm_plane *out)
 {
     if (!m) return SADBM_E_NULL;
-    int rc = check_pair(left, right, win, max_disp);
+    int rc = check_pair(left, right, win, max_disp, flags);
     if (rc) return rc;
     const int rows = left->rows, cols = left->cols, ch = left->channels, n = m->n;
     if (out && (out->rows != rows || out->cols != cols || out->step < cols)) return SADBM_E_SIZE;
@@ -464,7 +465,8 @@ int sadbm_compute_multi_device(sadbm_multi *m, int src_index, const uint8_t *dL,
     if (src_index < 0 || src_index >= m->n) return SADBM_E_PARAM;
     if (rows < 0 || cols < 0) return SADBM_E_SIZE;
     if (channels != 1 && channels != 3 && channels != 4) return SADBM_E_TYPE;
-    if (win < 1 || win > 255 || max_disp < 1 || max_disp > 256) return SADBM_E_PARAM;
+    if (win < 1 || max_disp < 1 || ((flags & SADBM_RAW_LOC) && max_disp > 256)) return SADBM_E_PARAM;
+    if (win > 4096 && rows > win && cols > win) return SADBM_E_PARAM;
     if (rows == 0 || cols == 0) return SADBM_OK;
     if (!dL || !dR) return SADBM_E_NULL;
     const int64_t rowb = (int64_t)cols * channels;
@@ -569,7 +571,7 @@ int sadbm_compute_multi_batch(sadbm_multi *m, const sadbm_image *lefts, const sa
     if (n_pairs == 0) return SADBM_OK;
     const int rows = lefts[0].rows, cols = lefts[0].cols, ch = lefts[0].channels, n = m->n;
     for (int p = 0; p < n_pairs; ++p) {
-        int rc = check_pair(&lefts[p], &rights[p], win, max_disp);
+        int rc = check_pair(&lefts[p], &rights[p], win, max_disp, flags);
         if (rc) return rc;
         if (lefts[p].rows != rows || lefts[p].cols != cols || lefts[p].channels != ch) return SADBM_E_SIZE;   // one geometry per batch
         if (outs[p].rows != rows || outs[p].cols != cols || outs[p].step < cols) return SADBM_E_SIZE;

@@ -165,8 +165,10 @@ __global__ void __launch_bounds__(256) zero_rows_kernel(uint8_t *out, int64_t ou
     for (int b = 0; b < 4 && x + b < cols; ++b) o[b] = 0;
 }
 
-// Brute-force matcher for any window (SADBM_FORCE_GENERIC): one thread per output
-// pixel, window SAD with v_sad_u8 on words from the padded planes.  Correctness path, not tuned.
+// Brute-force matcher for any window and any search range (SADBM_FORCE_GENERIC; windows beyond 255 columns): one thread per
+// output pixel, window SAD with v_sad_u8 on words from the padded planes.  Correctness path, not tuned.  Keys are 64-bit
+// (cost << 32 | k), and the cost takes the reference's round trip through `float sub_Sum` (SAD.cpp:10,20-21), which stops
+// being exact at 2^24, i.e. from 257 x 257 windows on.
 __global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -178,24 +180,27 @@ __global__ void __launch_bounds__(256) sad_generic_kernel(Params p)
     const int ocols = p.W - p.win;
     if (x >= ocols) { out[x] = 0; return; }
     const int kmax = min(x, p.D - 1);
-    uint32_t best = KEY_MAX;
+    uint64_t best = ~0ull;
     // four bytes per v_sad_u8 (byte-granular dword loads; the planes are padded, so the word that holds the window's last
     // 1-3 bytes is readable -- its other bytes are masked away in both operands)
     typedef uint32_t u32u __attribute__((aligned(1)));
     const int nw = p.win >> 2, rem = p.win & 3;
     const uint32_t tail_mask = rem ? (0xFFFFFFFFu >> (8 * (4 - rem))) : 0u;
     for (int k = 0; k <= kmax; ++k) {
-        uint32_t cost = 0;
+        uint32_t cost = 0;                                    // < 2^32 for win <= 4096
         for (int dy = 0; dy < p.win; ++dy) {
             const uint8_t *pl = L + (int64_t)(y + dy) * p.pitch + x;
             const uint8_t *pr = R + (int64_t)(y + dy) * p.pitch + x - k;
             for (int w = 0; w < nw; ++w) cost = __builtin_amdgcn_sad_u8(*(const u32u *)(pl + 4 * w), *(const u32u *)(pr + 4 * w), cost);
             if (rem) cost = __builtin_amdgcn_sad_u8(*(const u32u *)(pl + 4 * nw) & tail_mask, *(const u32u *)(pr + 4 * nw) & tail_mask, cost);
         }
-        best = min(best, (cost << 8) | (uint32_t)k);          // cost < 2^24 for win <= 255
+        // sub_Sum = (float)Add[0]; return (int)sub_Sum  (SAD.cpp:20-21); Temp.at<float> = that int (SAD.cpp:48): the compare of
+        // SAD.cpp:54 sees float(int(float(cost))) -- monotone in the middle value, which is an exact integer
+        const uint32_t c = (uint32_t)(int)(float)cost;
+        best = min(best, ((uint64_t)c << 32) | (uint32_t)k);
     }
-    if (x + 1 < p.D) best = min(best, (uint32_t)(x + 1));
-    uint32_t loc = best & 0xFFu;
+    if (x + 1 < p.D) best = min(best, (uint64_t)(uint32_t)(x + 1));
+    const uint32_t loc = (uint32_t)best;
     out[x] = (p.flags & SADBM_RAW_LOC) ? (uint8_t)loc : (uint8_t)((loc * 16u) & 0xFFu);
 }
 
@@ -246,7 +251,11 @@ __global__ void __launch_bounds__(256) sad_wide_kernel(Params p)
         for (int r = 0; r < ny + p.win - 1; ++r) {
             const bool leave = r >= p.win, emit = r >= p.win - 1;
             uint32_t rw[16], qw[16], lref = 0, mref = 0;
-            if (col_ok) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { rw[i] = 0; qw[i] = 0; }
+            // columns left of kg hold no competing slot in this pass (k > column, SAD.cpp:44) and feed no window that does: they
+            // load nothing, so the look-back stays within 63 columns of column 0 (the planes' left padding) whatever D is
+            if (col_ok && xc >= kg) {
                 // disparity kg + i pairs L[xc] with R[xc - kg - i]: the 64 bytes that end at R[xc - kg] (left padding: zeros)
                 const uint8_t *pr = R + (int64_t)r * p.pitch - kg - 63;
                 const uint32_t lb = L[(int64_t)r * p.pitch], lm = lb ? 0u : 0xFFFFFFFFu;
@@ -261,8 +270,10 @@ __global__ void __launch_bounds__(256) sad_wide_kernel(Params p)
                     for (int i = 0; i < 16; ++i) qw[i] = *(const u32u *)(qr + 4 * i) ^ mm;
                 }
             }
-            uint32_t b = KEY_MAX;
-            if (emit && out_ok && kg > 0) b = best_s[(r - (p.win - 1)) * 256 + tid];
+            // keys are cost << 8 | (k & 255): within a pass the minimum is the first minimum; across passes (ascending k, D up to
+            // any size) a later pass only wins with a strictly smaller cost (SAD.cpp:54)
+            uint32_t b = KEY_MAX, bprev = KEY_MAX;
+            if (emit && out_ok && kg > 0) bprev = best_s[(r - (p.win - 1)) * 256 + tid];
 #pragma unroll
             for (int c2 = 0; c2 < 4; ++c2) {           // two chunks of 8 disparities per exchange
                 if (kg + 16 * c2 < p.D) {              // uniform over the block (slots >= D of the pair are summed but never compete)
@@ -326,7 +337,7 @@ __global__ void __launch_bounds__(256) sad_wide_kernel(Params p)
 #pragma unroll
                                 for (int j = 0; j < 8; ++j) {
                                     const int sidx = 8 * h + (j < 4 ? 3 - j : 11 - j);
-                                    if (k0 + j <= kmax) b = min(b, (a[sidx] << 8) | (uint32_t)(k0 + j));
+                                    if (k0 + j <= kmax) b = min(b, (a[sidx] << 8) | (uint32_t)((k0 + j) & 255));
                                 }
                             }
                         }
@@ -334,10 +345,12 @@ __global__ void __launch_bounds__(256) sad_wide_kernel(Params p)
                 }
             }
             if (emit && tid < NX && xc < p.W) {
+                if ((bprev >> 8) <= (b >> 8)) b = bprev;             // KEY_MAX >> 8 exceeds every cost (< 2^24)
                 if (kg + 64 < p.D) {
                     if (out_ok) best_s[(r - (p.win - 1)) * 256 + tid] = b;
                 } else {
-                    if (xc + 1 < p.D) b = min(b, (uint32_t)(xc + 1));
+                    // slots k > column keep cost 0 (SAD.cpp:40): the first of them, k = column + 1, wins unless a valid slot has cost 0
+                    if (xc + 1 < p.D && (b >> 8) != 0) b = (uint32_t)((xc + 1) & 255);
                     const uint32_t loc = b & 0xFFu;
                     out[(int64_t)(r - (p.win - 1)) * p.out_pitch] = !out_ok ? (uint8_t)0 : (p.flags & SADBM_RAW_LOC) ? (uint8_t)loc : (uint8_t)((loc * 16u) & 0xFFu);
                 }
@@ -418,10 +431,14 @@ using sadbm_hostcopy::copy_rows;
 
 int check_params(int rows, int cols, int channels, int win, int max_disp, uint32_t flags)
 {
-    (void)flags;
     if (rows < 0 || cols < 0) return SADBM_E_SIZE;
     if (channels != 1 && channels != 3 && channels != 4) return SADBM_E_TYPE;
-    if (win < 1 || win > 255 || max_disp < 1 || max_disp > 256) return SADBM_E_PARAM;
+    // The reference takes any winSize / DSR (plain ints, SAD.cpp:9,11).  Here: raw loc output is a byte, so SADBM_RAW_LOC needs
+    // max_disp <= 256 (the reference's own encoding, (loc*16) mod 256, has no such limit); the brute-force matcher that serves
+    // windows beyond 255 columns sums costs in 32 bits, i.e. up to 4096 x 4096 windows.
+    if (win < 1 || max_disp < 1) return SADBM_E_PARAM;
+    if ((flags & SADBM_RAW_LOC) && max_disp > 256) return SADBM_E_PARAM;
+    if (win > 4096 && rows > win && cols > win) return SADBM_E_PARAM;
     return SADBM_OK;
 }
 
@@ -595,7 +612,7 @@ StripPlan plan_strip(int cus, bool host_inputs, int64_t pitchL, int64_t pitchR, 
     // matcher choice: SADBM_KERNEL_STRIP / SADBM_KERNEL_QUAD force one; env SADBM_MATCHER=strip|quad overrides the default
     bool use_strip = false;
     int strip_ng = D <= 64 ? 4 : D <= 128 ? 8 : 16;          // disparity groups of 16 per block (multiple of 4)
-    strip_kernel_t sk = (win <= MAXWIN && cols < 65000) ? pick_strip_kernel(win, strip::NS + strip_ng) : nullptr;
+    strip_kernel_t sk = (win <= MAXWIN && cols < 65000 && D <= 256) ? pick_strip_kernel(win, strip::NS + strip_ng) : nullptr;
     // short searches: the on-the-fly form (blocks of 1, 2 or 4 groups of 16 disparities, strip_otf_kernels.hip)
     int otf_lds = 0;
     int otf_ng = D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : 8;
@@ -709,6 +726,9 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     ctx->last_stream = st; ctx->has_last = true;
     if (nvalid < 0) nvalid = 0;
     if (cols - win <= 0) nvalid = 0;
+    // disparities k >= cols never compete (k > column, SAD.cpp:44) and the zero-cost slot that can win is k = column + 1 < cols:
+    // searching [0, cols) gives what [0, DSR) gives
+    if (D > cols) D = cols;
     // zero frame: rows [nvalid, rows_out) entirely (SAD.cpp:31,34); columns >= cols-win are written as zeros by the
     // matchers themselves.  The strip matcher also writes these rows (blocks of its last band), unless there are many.
     auto zero_rows = [&]() -> int {
@@ -796,7 +816,9 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         return SADBM_OK;
     }
 
-    if (win >= env().wide_from && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL))) {
+    // beyond 256 disparities (reference encoding only: (loc*16) mod 256, SAD.cpp:57) the column-sum matcher serves every window
+    // up to 255 columns: its 64-disparity passes merge by cost, so the key only needs k mod 256
+    if ((win >= env().wide_from || D > 256) && win <= 255 && !(flags & SADBM_FORCE_GENERIC) && !((flags & SADBM_KERNEL_GLOBAL) && D <= 256)) {
         const int NX = 257 - win;                                // output columns per block (win <= 255)
         // rows per block: every block sums win - 1 rows before its first output row, but a grid below a few blocks per CU
         // leaves the loads' and the exchanges' latency exposed (profiles/r02l_wide_windows.txt)
@@ -808,7 +830,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         if (g.y > 65535u || g.z > 65535u) return SADBM_E_SIZE;
         hipLaunchKernelGGL(sad_wide_kernel, g, dim3(256), (size_t)WIDE_LDS + (D > 64 ? (size_t)WIDE_TY * 256 * 4 : 0), st, p);
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_wide_kernel");
-    } else if ((win > MAXWIN && (flags & SADBM_KERNEL_GLOBAL)) || (flags & SADBM_FORCE_GENERIC)) {
+    } else if (win > 255 || (win > MAXWIN && (flags & SADBM_KERNEL_GLOBAL)) || (flags & SADBM_FORCE_GENERIC)) {
         dim3 g((cols + 255) / 256, nvalid, n_pairs);
         hipLaunchKernelGGL(sad_generic_kernel, g, dim3(256), 0, st, p);
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_generic_kernel");
@@ -928,7 +950,7 @@ const char *sadbm_strerror(int code)
     case SADBM_E_NULL: return "null pointer argument";
     case SADBM_E_TYPE: return "unsupported channel count or left/right channel mismatch";
     case SADBM_E_SIZE: return "bad image size or pitch (right must be at least as large as left)";
-    case SADBM_E_PARAM: return "bad parameter (need 1<=win<=255, 1<=max_disp<=256)";
+    case SADBM_E_PARAM: return "bad parameter (need win >= 1, max_disp >= 1; SADBM_RAW_LOC needs max_disp <= 256; windows beyond 4096 columns are not supported)";
     case SADBM_E_HIP: return "HIP runtime error";
     case SADBM_E_ALLOC: return "device memory allocation failed";
     case SADBM_E_BUSY: return "pipeline slot still in flight, or ticket unknown";
@@ -1017,6 +1039,7 @@ int sadbm_plan_describe(int rows, int cols, int channels, int n_pairs, int win, 
     int nvalid = rows - win;
     if (nvalid < 0 || cols - win <= 0) nvalid = 0;
     if (nvalid == 0 || rows == 0 || cols == 0) { snprintf(text, (size_t)text_len, "matcher=none"); return SADBM_OK; }
+    if (max_disp > cols) max_disp = cols;                     // as run_pipeline
     const StripPlan sp = plan_strip(cus, false, (int64_t)cols * channels, (int64_t)cols * channels, n_pairs, rows, nvalid, cols, channels, win,
                                     max_disp, flags);
     if (sp.use_strip) {
@@ -1026,9 +1049,9 @@ int sadbm_plan_describe(int rows, int cols, int channels, int n_pairs, int win, 
         snprintf(text, (size_t)text_len, "matcher=%s kernel=%s threads=%d FG=%d Wp=%d groups=%d bx=%d TY=%d nby=%d blocks=%ld tail=%d lds=%zu scratch=%zu prep=%d",
                  sp.use_otf ? "strip_otf" : "strip", name, 64 * sp.ng, sp.FG, sp.Wp, sp.n_groups, sp.bx, sp.TY, sp.nby, sp.nblocks, sp.tail, sp.lds,
                  sp.direct ? (size_t)0 : sp.planes_need, sp.direct ? 0 : 1);
-    } else if (win >= env().wide_from && !(flags & (SADBM_FORCE_GENERIC | SADBM_KERNEL_GLOBAL))) {
+    } else if ((win >= env().wide_from || max_disp > 256) && win <= 255 && !(flags & SADBM_FORCE_GENERIC) && !((flags & SADBM_KERNEL_GLOBAL) && max_disp <= 256)) {
         snprintf(text, (size_t)text_len, "matcher=wide kernel=sad_wide_kernel scratch=%zu prep=1", sp.planes_need);
-    } else if ((win > MAXWIN && (flags & SADBM_KERNEL_GLOBAL)) || (flags & SADBM_FORCE_GENERIC)) {
+    } else if (win > 255 || (win > MAXWIN && (flags & SADBM_KERNEL_GLOBAL)) || (flags & SADBM_FORCE_GENERIC)) {
         snprintf(text, (size_t)text_len, "matcher=generic kernel=sad_generic_kernel scratch=%zu prep=1", sp.planes_need);
     } else if (flags & SADBM_KERNEL_GLOBAL) {
         snprintf(text, (size_t)text_len, "matcher=quad kernel=sad_quad_kernel<%d> scratch=%zu prep=1", win, sp.planes_need);

@@ -87,7 +87,7 @@ def test_argument_validation_happens_before_device_use():
     assert f(fake, ctypes.byref(img(8, 8, 1)), ctypes.byref(img(7, 8, 1)), 3, 8, 0, ctypes.byref(pl)) == -3
     assert f(fake, ctypes.byref(img(8, 8, 1)), ctypes.byref(img(8, 8, 1)), 0, 8, 0, ctypes.byref(pl)) == -4
     assert f(fake, ctypes.byref(img(8, 8, 1)), ctypes.byref(img(8, 8, 1)), 3, 0, 0, ctypes.byref(pl)) == -4
-    assert f(fake, ctypes.byref(img(8, 8, 1)), ctypes.byref(img(8, 8, 1)), 3, 257, 0, ctypes.byref(pl)) == -4
+    assert f(fake, ctypes.byref(img(8, 8, 1)), ctypes.byref(img(8, 8, 1)), 3, 257, 1, ctypes.byref(pl)) == -4   # raw loc is a byte: DSR <= 256
     g = lib.sadbm_compute_device
     assert g(None, 1, 8, 1, 8, 8, 8, 1, 3, 8, 0, 1, 8, None) == -1
     assert g(fake, 1, 4, 1, 8, 8, 8, 1, 3, 8, 0, 1, 8, None) == -3        # pitch < row bytes

@@ -158,6 +158,9 @@ def test_errors_match_reference_failure_modes():
     with pytest.raises(oa.SadbmError) as e:
         oa.get_disparity_host(L, R, 0, 30)
     assert e.value.code == -4
+    with pytest.raises(oa.SadbmError) as e:                      # raw loc output is a byte; the reference's encoding has no such limit
+        oa.get_disparity_host(L, R, 7, 257, oa.RAW_LOC)
+    assert e.value.code == -4
 
 
 def test_batch_matches_per_pair():
@@ -314,3 +317,59 @@ def test_wide_windows_column_sum_matcher(win):
         i1 = min(r0 + nb + win - 1, H)
         got = oa.compute_band_device(dev(L[r0:i1]), dev(R[r0:i1]), H, r0, nb, win, D).cpu().numpy()
         assert np.array_equal(got, full[r0:r0 + nb]), (win, r0, nb)
+
+
+@pytest.mark.parametrize("D", [257, 300, 512, 1000])
+def test_search_ranges_beyond_256_disparities(D):
+    """SAD.cpp:11 `int DSR` has no upper limit and SAD.cpp:57 stores (loc*16) mod 256: DSR > 256 is a legal input (SURVEY b2 limits only
+    the raw-loc output).  The column-sum matcher serves it for every window up to 255 columns: 64-disparity passes merged by cost,
+    keys carry k mod 256.  Against oracle.literal (and oracle.box on the larger frames): frames wider and narrower than DSR, binary dots
+    (cost ties across the 256-disparity boundary: the earlier disparity must win), batches, a row band, BGR, the host API."""
+    from helpers import kname
+    for (H, W, win, binary, shift) in ((23, 700, 7, False, 290), (30, 1100, 9, True, 300), (19, 420, 15, True, 263), (40, 600, 21, False, 5), (12, 280, 4, True, 270),
+                                       (70, 640, 51, True, 259)):
+        L, R = noise_pair(D + win, H, W, shift=min(shift, W - 1), binary=binary)
+        exp = oracle.literal(L, R, win, D) if H * W <= 30000 else oracle.box(L, R, win, D)
+        ctx = oa.Context(0)
+        got = oa.compute_device(dev(L), dev(R), win, D, ctx=ctx).cpu().numpy()
+        assert kname(ctx) == "sad_wide_kernel"
+        assert np.array_equal(got, exp), (D, H, W, win, np.argwhere(got != exp)[:4])
+        assert np.array_equal(oa.get_disparity_host(L, R, win, D), exp), ("host", D, H, W, win)
+    # constant images: every valid cost equal, loc = j + 1 up to DSR - 1 and 0 beyond (K2), encoded mod 256
+    c1, c2 = np.full((12, D + 40), 7, np.uint8), np.full((12, D + 40), 9, np.uint8)
+    got = oa.compute_device(dev(c1), dev(c2), 5, D).cpu().numpy()
+    exp = np.zeros_like(c1)
+    for j in range(D + 40 - 5):
+        exp[:12 - 5, j] = (((j + 1) if j + 1 < D else 0) * 16) & 255
+    assert np.array_equal(got, exp)
+    # batch + band + BGR
+    Ls, Rs = zip(*[noise_pair(900 + i, 33, 530, shift=280 + i, binary=True) for i in range(3)])
+    out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), 9, D).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], 9, D)), i
+    full = oracle.box(Ls[0], Rs[0], 9, D)
+    got = oa.compute_band_device(dev(Ls[0][10:33]), dev(Rs[0][10:33]), 33, 10, 23, 9, D).cpu().numpy()
+    assert np.array_equal(got, full[10:33])
+    L3, R3 = noise_pair(77, 20, 400, shift=300, ch=3)
+    assert np.array_equal(oa.get_disparity_host(L3, R3, 7, D), oracle.literal(np.ascontiguousarray(L3[:, :, 0]), np.ascontiguousarray(R3[:, :, 0]), 7, D))
+
+
+@pytest.mark.parametrize("win", [256, 257, 260, 300])
+def test_windows_beyond_255_columns(win):
+    """SAD.cpp:9 `int winSize` has no upper limit either.  Windows beyond 255 columns run the brute-force matcher with 64-bit keys; from
+    257 x 257 on the reference's cost passes through `float sub_Sum` inexactly (SAD.cpp:10,20-21: 257^2 * 255 > 2^24) -- binary dots
+    drive costs up there -- and oracle.literal, which keeps the float, is the oracle."""
+    from helpers import kname
+    for (H, W, D, binary) in ((win + 3, win + 9, 6, True), (win + 2, win + 5, 300, False)):
+        L, R = noise_pair(win + D, H, W, shift=2, binary=binary)
+        if binary:                                              # make the windows differ almost everywhere: costs near win^2 * 255
+            R = np.where(L > 0, 0, 255).astype(np.uint8)
+            R[::7, ::5] = L[::7, ::5]
+        exp = oracle.literal(L, R, win, D)
+        ctx = oa.Context(0)
+        got = oa.compute_device(dev(L), dev(R), win, D, ctx=ctx).cpu().numpy()
+        assert kname(ctx) == "sad_generic_kernel"
+        assert np.array_equal(got, exp), (win, H, W, D, np.argwhere(got != exp)[:4])
+    # a window as large as the frame: nothing to compute (SAD.cpp:34,36), whatever its size
+    L, R = noise_pair(1, 40, 50)
+    assert not oa.get_disparity_host(L, R, 5000, 30).any()

@@ -31,11 +31,21 @@ def test_baseline_configurations_get_the_documented_kernels():
 
 
 def test_plan_rejects_what_the_calls_reject():
-    for args, code in (((10, 10, 2, 1, 7, 30), -2), ((10, 10, 1, 1, 0, 30), -4), ((10, 10, 1, 1, 7, 0), -4), ((10, 10, 1, 1, 7, 257), -4),
-                       ((10, 10, 1, 0, 7, 30), -3)):
+    for args, code in (((10, 10, 2, 1, 7, 30), -2), ((10, 10, 1, 1, 0, 30), -4), ((10, 10, 1, 1, 7, 0), -4), ((10, 10, 1, 1, 7, 257, oa.RAW_LOC), -4),
+                       ((5000, 5000, 1, 1, 4097, 30), -4), ((10, 10, 1, 0, 7, 30), -3)):
         with pytest.raises(oa.SadbmError) as e:
             oa.plan(*args)
         assert e.value.code == code, args
+
+
+def test_plan_beyond_256_disparities_and_255_columns():
+    """The reference limits neither winSize nor DSR (SAD.cpp:9,11): beyond 256 disparities the column-sum matcher runs (any window up to
+    255 columns), beyond 255 columns the brute force; a search wider than the frame is the search over [0, cols)."""
+    assert oa.plan(400, 700, 1, 1, 7, 300)["matcher"] == "wide"
+    assert oa.plan(400, 700, 1, 1, 21, 5000)["matcher"] == "wide"
+    assert oa.plan(400, 200, 1, 1, 7, 300)["kernel"] == oa.plan(400, 200, 1, 1, 7, 200)["kernel"]      # D clamps to cols
+    assert oa.plan(400, 700, 1, 1, 300, 30)["matcher"] == "generic"
+    assert oa.plan(100, 100, 1, 1, 5000, 30)["matcher"] == "none"
 
 
 def test_strip_plans_cover_the_job():
@@ -63,9 +73,10 @@ def test_strip_plans_cover_the_job():
         assert p["blocks"] == bx * nby * groups, what
         assert 0 <= p["tail"] <= (p["blocks"] + 7) // 8 // 2, what
         assert p["lds"] <= 160 * 1024 and p["threads"] in (64, 128, 256, 512, 1024), what
-        assert 16 * (p["threads"] // 64) >= D, what                                      # the block's disparity slots cover the search
+        Deff = min(D, cols)                                                              # disparities >= cols never compete (SAD.cpp:44)
+        assert 16 * (p["threads"] // 64) >= Deff, what                                   # the block's disparity slots cover the search
         if p["matcher"] == "strip_otf":
-            assert D <= 128 and p["lds"] <= 16 * 1024, what
+            assert Deff <= 128 and p["lds"] <= 16 * 1024, what
             assert (p["prep"] == 0) == p["kernel"].endswith("+direct") and (p["prep"] == 1 or (ch == 1 and p["scratch"] == 0)), what
         else:
             assert p["prep"] == 1 and p["scratch"] > 2 * (rows - 1) * cols * groups, what

@@ -595,7 +595,7 @@ bool otf_is_default(int win, int D, int cols, int rows, int n_pairs)
 // frame groups, whether the inputs are read in place, the scratch planes and the grid.  No HIP calls: sadbm_plan_describe()
 // exposes it, and the CPU-only tests check the policy and its invariants through that.
 struct StripPlan {
-    bool use_strip = false, use_otf = false, direct = false, strip_zeroes = false;
+    bool use_strip = false, use_otf = false, direct = false, sdirect = false, strip_zeroes = false;
     int ng = 0;                           // groups of 16 disparities per block (block = 64 ng threads)
     int FG = 1, Wp = 0, n_groups = 0, vcols = 0, pitch = 0;
     size_t plane_bytes = 0, planes_need = 0;
@@ -604,8 +604,9 @@ struct StripPlan {
     size_t lds = 0;
     strip_kernel_t kernel = nullptr;
 };
+constexpr int SDIRECT_NEDGE = 2;
 StripPlan plan_strip(int cus, bool host_inputs, int64_t pitchL, int64_t pitchR, int n_pairs, int rows_out, int nvalid, int cols,
-                     int channels, int win, int D, uint32_t flags)
+                     int channels, int win, int D, uint32_t flags, bool sdirect_ok = true)
 {
     StripPlan sp;
     const int need_rows = nvalid + win - 1;
@@ -647,7 +648,17 @@ StripPlan plan_strip(int cus, bool host_inputs, int64_t pitchL, int64_t pitchR, 
         strip_frame_groups(cols, n_pairs, true, &FG, &Wp, &blocksg);
         sk = pick_strip_otf_kernel(win, otf_ng, true, &otf_lds);
     }
-    if (use_strip && !direct && ((size_t)(PADL + (size_t)(FG - 1) * Wp + cols + PADR + 127) & ~(size_t)127) * (size_t)need_rows > 0x7ff00000u) {
+    // The staged kernel reads single-channel device images in place as well (round 3: no prep pass, no scratch planes; step traffic
+    // 2.1-2.5x -> 1.1x the algorithmic 3 W H): its staging offsets are 32-bit from one base, so both batches must share a row
+    // pitch and lie within 4 GB of each other (sdirect_ok: run_pipeline checks the pointers).
+    // Rows that a 16-byte unit cannot load without leaving its batch are assembled byte-wise into SDIRECT_NEDGE spare row images in
+    // LDS: with a pitch of 384 bytes and more these are at most the first row of the batch (look-back <= 275 bytes left of column
+    // 0) and its last one (windows reach <= 330 bytes past the row's end).  256-thread blocks (D <= 64 under SADBM_OTF=0, 4-wide
+    // windows) keep the planes: four of them share a CU's LDS, the spare row images would cost one.
+    const bool sdirect = use_strip && !use_otf && channels == 1 && !host_inputs && env().direct != 0 && sdirect_ok && pitchL == pitchR &&
+                         pitchL >= 384 && pitchL < 0x7ff00000LL && cols + 32 < 65000 && strip_ng >= 8;
+    if (sdirect) strip_frame_groups(cols, n_pairs, true, &FG, &Wp, &blocksg);
+    if (use_strip && !direct && !sdirect && ((size_t)(PADL + (size_t)(FG - 1) * Wp + cols + PADR + 127) & ~(size_t)127) * (size_t)need_rows > 0x7ff00000u) {
         FG = 1; Wp = cols;                                    // the strip matcher addresses the R plane with 32-bit offsets
         if ((size_t)((PADL + cols + PADR + 127) & ~127) * (size_t)need_rows > 0x7ff00000u) use_strip = false;
     }
@@ -659,7 +670,7 @@ StripPlan plan_strip(int cus, bool host_inputs, int64_t pitchL, int64_t pitchR, 
     // scratch layout: [group][L plane | R plane], + slack: the strip matcher stages whole 256-column blocks
     // and may read a few hundred bytes past the last row (values only reach columns >= cols-win, which are 0)
     const size_t planes_need = 2 * plane_bytes * (size_t)n_groups + 4096;
-    sp.use_strip = use_strip; sp.use_otf = use_strip && use_otf; sp.direct = direct; sp.strip_zeroes = strip_zeroes;
+    sp.use_strip = use_strip; sp.use_otf = use_strip && use_otf; sp.direct = direct; sp.sdirect = use_strip && sdirect; sp.strip_zeroes = strip_zeroes;
     sp.ng = strip_ng; sp.FG = FG; sp.Wp = Wp; sp.n_groups = n_groups; sp.vcols = vcols; sp.pitch = pitch;
     sp.plane_bytes = plane_bytes; sp.planes_need = planes_need; sp.kernel = sk;
     if (!use_strip) return sp;
@@ -671,7 +682,7 @@ StripPlan plan_strip(int cus, bool host_inputs, int64_t pitchL, int64_t pitchR, 
     const int TY = (use_otf && strip_ng <= 4) ? otf_band_rows(bx, n_groups, nvalid, win, strip_ng, cus) : strip_band_rows(bx, n_groups, nvalid, win, strip_ng, cus);
     int PR = 0, ROWW = 0;
     if (!use_otf) strip_geometry(win, strip::NS + strip_ng, &PR, &ROWW);
-    sp.lds = use_otf ? (size_t)otf_lds : (size_t)(4 * ROWW + 3 * 64 * PR + 2 * 4 * 64 + 64) * 4;
+    sp.lds = use_otf ? (size_t)otf_lds : (size_t)(4 * ROWW + 3 * 64 * PR + 2 * 4 * 64 + 64 + 8 + (sdirect ? SDIRECT_NEDGE * ROWW : 0)) * 4;
     sp.bx = bx; sp.TY = TY; sp.nby = (nvalid + TY - 1) / TY;
     sp.nblocks = (long)sp.bx * sp.nby * n_groups;
     const long chunk_units = (sp.nblocks + 7) / 8;            // per XCD
@@ -745,8 +756,14 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
     const int need_rows = nvalid + win - 1;                   // <= rows_in (checked by callers)
 
     // matcher choice, frame groups, direct reads, grid shape of the strip family: plan_strip (no HIP calls in it)
-    const StripPlan sp = plan_strip(ctx->cus, ctx->host_inputs, pitchL, pitchR, n_pairs, rows_out, nvalid, cols, channels, win, D, flags);
-    const bool use_strip = sp.use_strip, use_otf = sp.use_otf, direct = sp.direct, strip_zeroes = sp.strip_zeroes;
+    // direct form of the staged kernel: 32-bit staging offsets from SDIRECT_BIAS below the lower batch must reach every byte of both
+    const uint8_t *sd_base = dL < dR ? dL : dR;
+    const int64_t sd_ext_l = (int64_t)(n_pairs - 1) * pair_stride_in + (int64_t)(need_rows - 1) * pitchL + cols;
+    const int64_t sd_ext_r = (int64_t)(n_pairs - 1) * pair_stride_in + (int64_t)(need_rows - 1) * pitchR + cols;
+    const int64_t sd_ll = (int64_t)(dL - sd_base) + strip::SDIRECT_BIAS, sd_lr = (int64_t)(dR - sd_base) + strip::SDIRECT_BIAS;
+    const bool sdirect_ok = pair_stride_in >= 0 && sd_ll + sd_ext_l + 65536 < 0xF0000000LL && sd_lr + sd_ext_r + 65536 < 0xF0000000LL;
+    const StripPlan sp = plan_strip(ctx->cus, ctx->host_inputs, pitchL, pitchR, n_pairs, rows_out, nvalid, cols, channels, win, D, flags, sdirect_ok);
+    const bool use_strip = sp.use_strip, use_otf = sp.use_otf, direct = sp.direct || sp.sdirect, strip_zeroes = sp.strip_zeroes;
     const int FG = sp.FG, Wp = sp.Wp, n_groups = sp.n_groups, pitch = sp.pitch;
     const size_t plane_bytes = sp.plane_bytes, planes_need = sp.planes_need;
     const strip_kernel_t sk = sp.kernel;
@@ -792,8 +809,15 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         q.pitch = pitch; q.W = cols; q.nvalid = nvalid; q.win = win; q.D = D;
         q.out = dOut; q.out_pitch = out_pitch; q.out_stride = pair_stride_out; q.flags = flags; q.dword_store = p.dword_store;
         q.dL = dL; q.dR = dR; q.in_stride = pair_stride_in; q.pitchL = (int)pitchL; q.pitchR = (int)pitchR;
-        q.extL = direct ? (int)((int64_t)(need_rows - 1) * pitchL + cols) : 0;
-        q.extR = direct ? (int)((int64_t)(need_rows - 1) * pitchR + cols) : 0;
+        q.extL = sp.direct ? (int)((int64_t)(need_rows - 1) * pitchL + cols) : 0;
+        q.extR = sp.direct ? (int)((int64_t)(need_rows - 1) * pitchR + cols) : 0;
+        q.sdirect = sp.sdirect ? 1 : 0; q.nedge = sp.sdirect ? SDIRECT_NEDGE : 0; q.ll_delta = 0; q.loA = q.lenA = q.loB = q.lenB = 0;
+        if (sp.sdirect) {
+            q.Lrow0 = sd_base - strip::SDIRECT_BIAS;          // an address, never dereferenced below sd_base
+            q.pair_stride = (int64_t)FG * pair_stride_in; q.pitch = (int)pitchL;
+            q.ll_delta = (uint32_t)sd_ll; q.lr_delta = (uint32_t)sd_lr;
+            q.loA = sd_ll; q.lenA = sd_ext_l; q.loB = sd_lr; q.lenB = sd_ext_r;
+        }
         const int TY = sp.TY;
         const size_t lds = sp.lds;
         q.TY = TY;
@@ -811,6 +835,7 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         hipLaunchKernelGGL(sk, g, dim3(64 * q.NG), lds, st, q);
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), use_otf ? "sad_strip_otf_kernel<%d>" : "sad_strip_kernel<%d>", win);
         if (use_otf) snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_strip_otf_kernel<%d,%d>%s", win, sp.ng, direct ? "+direct" : "");
+        else if (sp.sdirect) snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "sad_strip_kernel<%d>+direct", win);
         HIPCHK(hipGetLastError());
         if (prof) { HIPCHK(hipEventRecord(ev[2], st)); ctx->ev_n++; }
         return SADBM_OK;
@@ -1045,10 +1070,10 @@ int sadbm_plan_describe(int rows, int cols, int channels, int n_pairs, int win, 
     if (sp.use_strip) {
         char name[64];
         if (sp.use_otf) snprintf(name, sizeof(name), "sad_strip_otf_kernel<%d,%d>%s", win, sp.ng, sp.direct ? "+direct" : "");
-        else snprintf(name, sizeof(name), "sad_strip_kernel<%d>", win);
+        else snprintf(name, sizeof(name), "sad_strip_kernel<%d>%s", win, sp.sdirect ? "+direct" : "");
         snprintf(text, (size_t)text_len, "matcher=%s kernel=%s threads=%d FG=%d Wp=%d groups=%d bx=%d TY=%d nby=%d blocks=%ld tail=%d lds=%zu scratch=%zu prep=%d",
                  sp.use_otf ? "strip_otf" : "strip", name, 64 * sp.ng, sp.FG, sp.Wp, sp.n_groups, sp.bx, sp.TY, sp.nby, sp.nblocks, sp.tail, sp.lds,
-                 sp.direct ? (size_t)0 : sp.planes_need, sp.direct ? 0 : 1);
+                 (sp.direct || sp.sdirect) ? (size_t)0 : sp.planes_need, (sp.direct || sp.sdirect) ? 0 : 1);
     } else if ((win >= env().wide_from || max_disp > 256) && win <= 255 && !(flags & SADBM_FORCE_GENERIC) && !((flags & SADBM_KERNEL_GLOBAL) && max_disp <= 256)) {
         snprintf(text, (size_t)text_len, "matcher=wide kernel=sad_wide_kernel scratch=%zu prep=1", sp.planes_need);
     } else if (win > 255 || (win > MAXWIN && (flags & SADBM_KERNEL_GLOBAL)) || (flags & SADBM_FORCE_GENERIC)) {

@@ -38,6 +38,7 @@ struct Params {
 
 namespace strip {
 constexpr int NS = 16;                 // strips per block
+constexpr int SDIRECT_BIAS = 512;      // >= the longest look-back of a staging unit (16 * 16 + 3 columns, + 16)
 constexpr int XBW = NS * 16;           // output columns per block
 struct SParams {
     const uint8_t *Lrow0;     // padded L plane of group 0, first byte of row 0 (column -PADL)
@@ -53,6 +54,13 @@ struct SParams {
     const uint8_t *dL, *dR;
     int64_t in_stride;
     int pitchL, pitchR, extL, extR;
+    // direct form of sad_strip_kernel (sdirect != 0): no padded planes either -- Lrow0 is a byte address SDIRECT_BIAS below the lower
+    // of the two image batches, staging offsets are 32-bit from there (ll_delta / lr_delta: where the L / R batch starts, bias
+    // included), pitch is the images' common row pitch, pair_stride = FG * in_stride.  [loA, loA + lenA) and [loB, loB + lenB) are
+    // the byte ranges (offsets from Lrow0) that may be read: the two batches.
+    int sdirect, nedge;       // nedge: spare row images in LDS for the rows that cannot be loaded whole (first / last row of a batch)
+    uint32_t ll_delta;
+    int64_t loA, lenA, loB, lenB;
     uint8_t *out;
     int64_t out_pitch, out_stride;
     uint32_t flags;

@@ -50,10 +50,12 @@ def noise_pair(seed, H, W, shift=None, binary=False, ch=1):
     return L, R
 
 
-def strip_kernel_name(win, D, staged=False):
-    """Which member of the strip family run_pipeline launches under KERNEL_STRIP (sadbm.hip, otf_is_default): the
+def strip_kernel_name(win, D, staged=False, cols=None):
+    """(cols: the frame width -- a search wider than the frame is run as the search over [0, cols), SAD.cpp:44.)  Which member of the strip family run_pipeline launches under KERNEL_STRIP (sadbm.hip, otf_is_default): the
     on-the-fly form for searches of at most 64 disparities (and narrow windows at 65-128 disparities that are not a multiple
     of 16), unless SADBM_OTF=0 (`staged`)."""
+    if cols is not None:
+        D = min(D, cols)
     if not staged and ((D <= 64 and (win >= 5 or D <= 16)) or (64 < D <= 128 and D % 16 and 5 <= win <= 11 and win != 10)):
         return "sad_strip_otf_kernel<%d,%d>" % (win, 1 if D <= 16 else 2 if D <= 32 else 4 if D <= 64 else 8)
     return "sad_strip_kernel<%d>" % win

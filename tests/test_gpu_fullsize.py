@@ -28,7 +28,7 @@ def test_config3_whole_4k_frame():
     exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
     ctx = oa.Context(0)
     got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC, ctx=ctx).cpu().numpy()
-    assert ctx.last_kernel() == "sad_strip_kernel<15>"
+    assert ctx.last_kernel() == "sad_strip_kernel<15>+direct"      # single-channel device frames are read in place
     assert_same(got, exp, "cfg3 raw")
     enc = oa.compute_device(dev(L), dev(R), win, D, ctx=ctx).cpu().numpy()
     assert_same(enc, ((exp.astype(np.int32) * 16) & 255).astype(np.uint8), "cfg3 encoded")    # SAD.cpp:57

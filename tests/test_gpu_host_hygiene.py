@@ -47,8 +47,9 @@ def test_short_lived_threads_do_not_leak_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert not errs, errs[:3]
-    # a leaked context holds >= 0.3 MB of device memory (planes + staging); 100 of them would be >= 30 MB
-    assert free0 - free1 < 8 << 20, (free0, free1)
+    # a leaked context holds >= 0.3 MB of device memory (planes + staging); 100 of them would be >= 30 MB.  (The runtime itself
+    # takes memory in 8 MB steps -- one such step was seen once in ten runs -- hence 16 MB and not less.)
+    assert free0 - free1 < 16 << 20, (free0, free1)
 
 
 def test_one_context_on_two_streams_and_two_threads():

@@ -35,7 +35,7 @@ def test_strip_small(win, D, form):
             exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
             ctx = oa.Context(0)
             got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
-            assert kname(ctx) == strip_kernel_name(win, D, form)
+            assert kname(ctx) == strip_kernel_name(win, D, form, cols=W)
             bad = np.argwhere(got != exp)
             assert bad.size == 0, (win, D, H, W, binary, len(bad), bad[:8], got[tuple(bad[0])], exp[tuple(bad[0])])
 
@@ -74,7 +74,7 @@ def test_strip_full_size_4k_band():
     L, R = oracle.rds(3, W, H, 16, 96, 0)
     ctx = oa.Context(0)
     got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
-    assert ctx.last_kernel() == "sad_strip_kernel<15>"
+    assert kname(ctx) == "sad_strip_kernel<15>"
     assert not got[H - win:, :].any() and not got[:, W - win:].any()
     assert (got[10, :16] == np.arange(1, 17)).all()
     assert (got[100, 200:900] == 16).all() and (got[1000, 1200:2700] == 96).all()
@@ -93,7 +93,7 @@ def test_strip_short_searches_batches_bands_and_borders(form):
         Ls, Rs = zip(*[oracle.rds(70 + i, W, H, 2 + i % 3, min(D - 1, 12 + i), i & 1) for i in range(n)])
         ctx = oa.Context(0)
         out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
-        assert kname(ctx) == strip_kernel_name(win, D, form)
+        assert kname(ctx) == strip_kernel_name(win, D, form, cols=W)
         for i in range(n):
             assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), (H, W, win, D, i)
         r0, nb = H // 3, H // 3
@@ -137,11 +137,12 @@ def test_strip_constant_identical_and_binary_ties():
 def test_strip_every_window_instantiation(win, form):
     """Every window the strip matchers are instantiated for (their geometry is constexpr per WIN), at every block size:
     16 / 32 / 64 disparities (on-the-fly form, or 64-disparity blocks of the staged form) and 128 / 256."""
-    L, R = noise_pair(900 + win, 57, 283, shift=7)
+    W = 283
+    L, R = noise_pair(900 + win, 57, W, shift=7)
     for D in ((9, 16, 30, 32, 50, 64) if not form else (9, 30, 50)) + (97, 256):
         ctx = oa.Context(0)
         got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
-        assert kname(ctx) == strip_kernel_name(win, D, form)
+        assert kname(ctx) == strip_kernel_name(win, D, form, cols=W)
         assert np.array_equal(got, oracle.box(L, R, win, D, oracle.RAW_LOC)), (win, D)
 
 
@@ -181,7 +182,7 @@ def test_strip_frame_groups(shape, pairs, monkeypatch, form):
             oa.reload_env()
             ctx = oa.Context(0)
             out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, oa.KERNEL_STRIP, ctx=ctx).cpu().numpy()
-            assert kname(ctx) == (strip_kernel_name(win, D, form) if H > win and W > win else "none")
+            assert kname(ctx) == (strip_kernel_name(win, D, form, cols=W) if H > win and W > win else "none")
             for i in range(pairs):
                 bad = np.argwhere(out[i] != exp[i])
                 assert bad.size == 0, (shape, pairs, win, D, fg, i, len(bad), bad[:6])
@@ -216,7 +217,7 @@ def test_direct_reads_of_caller_images(win, D, monkeypatch):
         ctx = oa.Context(0)
         # exact-size allocations: nothing readable before the first or after the last byte
         got = oa.compute_device(dev(L), dev(R), win, D, 0, ctx=ctx).cpu().numpy()
-        assert ctx.last_kernel() == strip_kernel_name(win, D) + "+direct", ctx.last_kernel()
+        assert ctx.last_kernel() == strip_kernel_name(win, D, cols=W) + "+direct", ctx.last_kernel()
         assert np.array_equal(got, exp), (H, W, "exact")
         # ROI views: left inside a wider buffer at a column offset, right inside a taller and wider one (its own pitch)
         bl = torch.from_numpy(rng.integers(0, 256, size=(H, W + 37), dtype=np.uint8)).cuda()
@@ -231,7 +232,7 @@ def test_direct_reads_of_caller_images(win, D, monkeypatch):
         monkeypatch.setenv("SADBM_DIRECT", "0")
         oa.reload_env()
         got0 = oa.compute_device(dev(L), dev(R), win, D, 0, ctx=ctx).cpu().numpy()
-        assert ctx.last_kernel() == strip_kernel_name(win, D)
+        assert ctx.last_kernel() == strip_kernel_name(win, D, cols=W)
         assert np.array_equal(got0, exp)
         if D <= 16 and win >= 13:
             monkeypatch.setenv("SADBM_DIRECT", "1")
@@ -268,7 +269,7 @@ def test_direct_reads_with_frame_groups(W, monkeypatch):
         bl[:, 1:1 + H, 5:5 + W] = dev(np.stack(Ls)); br[:, 1:1 + H, 5:5 + W] = dev(np.stack(Rs))
         ctx = oa.Context(0)
         out = oa.compute_batch_device(bl[:, 1:1 + H, 5:5 + W], br[:, 1:1 + H, 5:5 + W], win, D, 0, ctx=ctx).cpu().numpy()
-        assert ctx.last_kernel() == strip_kernel_name(win, D) + "+direct"
+        assert ctx.last_kernel() == strip_kernel_name(win, D, cols=W) + "+direct"
         for i in range(n):
             assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), ("view", W, win, D, i)
     monkeypatch.setenv("SADBM_DIRECT", "1")
@@ -277,7 +278,7 @@ def test_direct_reads_with_frame_groups(W, monkeypatch):
         Ls, Rs = zip(*[noise_pair(W + 11 * i + win, H, W, shift=min(3 + i, W - 1), binary=bool(i & 1)) for i in range(n)])
         ctx = oa.Context(0)
         out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, 0, ctx=ctx).cpu().numpy()
-        assert ctx.last_kernel() == strip_kernel_name(win, D) + "+direct"
+        assert ctx.last_kernel() == strip_kernel_name(win, D, cols=W) + "+direct"
         for i in range(n):
             assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), (W, win, D, i)
 
@@ -344,3 +345,62 @@ def test_packed_word_sums_of_windows_17_to_21(win, form):
             exp = oracle.box(L, R, win, D, oracle.RAW_LOC)
             got = oa.compute_device(dev(L), dev(R), win, D, oa.RAW_LOC | oa.KERNEL_STRIP).cpu().numpy()
             assert np.array_equal(got, exp), (win, D, np.argwhere(got != exp)[:4])
+
+
+@pytest.mark.parametrize("win,D", [(7, 128), (15, 128), (21, 256), (9, 80), (13, 200), (17, 96), (25, 130), (5, 256)])
+def test_staged_kernel_reads_caller_images(win, D, monkeypatch):
+    """Round 3: sad_strip_kernel reads single-channel device images in place too ("+direct": no prep pass, no scratch planes).  Its edge rows
+    -- the first row of a batch (look-back left of column 0) and the last one (16-byte windows past the end) -- are assembled byte-wise
+    into spare row images before the march.  Exact-size allocations (nothing readable before the first or after the last byte), ROI views
+    inside larger buffers, pitch == cols, frame groups of a batch, several bands, a row band, binary dots; equal to the oracle and to the
+    prep-pass path (SADBM_DIRECT=0).  Left and right with different pitches, and rows shorter than 384 bytes, keep the planes."""
+    import torch
+    rng = np.random.default_rng(win * 1000 + D)
+    for (H, W, binary) in ((win + 3, 384, False), (win + 40, 517, True), (win + 2, 1000, False), (130, 400, False), (win + 70, 2048, True)):
+        L, R = noise_pair(H * 7 + W + D, H, W, shift=min(5, W - 1), binary=binary)
+        exp = oracle.box(L, R, win, D)
+        ctx = oa.Context(0)
+        got = oa.compute_device(dev(L), dev(R), win, D, 0, ctx=ctx).cpu().numpy()                 # exact-size allocations
+        assert ctx.last_kernel() == "sad_strip_kernel<%d>+direct" % win, ctx.last_kernel()
+        assert np.array_equal(got, exp), (H, W, "exact", np.argwhere(got != exp)[:4])
+        # ROI views with a common pitch: left at a column offset of one buffer, right at another offset of an equally wide one
+        bl = torch.from_numpy(rng.integers(0, 256, size=(H + 1, W + 80), dtype=np.uint8)).cuda()
+        br = torch.from_numpy(rng.integers(0, 256, size=(H + 3, W + 80), dtype=np.uint8)).cuda()
+        bl[1:1 + H, 5:5 + W] = dev(L); br[2:2 + H, 41:41 + W] = dev(R)
+        got = oa.compute_device(bl[1:1 + H, 5:5 + W], br[2:2 + H, 41:41 + W], win, D, 0, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel().endswith("+direct")
+        assert np.array_equal(got, exp), (H, W, "roi")
+        # the same image on both sides (one batch is the other): loc 0 everywhere (K1)
+        same = oa.compute_device(dev(L), dev(L), win, D, oa.RAW_LOC, ctx=ctx)
+        assert ctx.last_kernel().endswith("+direct") and not same.any()
+        # different pitches: the planes (the direct form addresses both images from one base with one pitch)
+        Rb = rng.integers(0, 256, size=(H + 2, W + 9), dtype=np.uint8); Rb[:H, :W] = R
+        got = oa.compute_device(dev(L), dev(Rb), win, D, 0, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel() == "sad_strip_kernel<%d>" % win
+        assert np.array_equal(got, exp), (H, W, "larger right")
+        monkeypatch.setenv("SADBM_DIRECT", "0")
+        oa.reload_env()
+        got0 = oa.compute_device(dev(L), dev(R), win, D, 0, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel() == "sad_strip_kernel<%d>" % win
+        assert np.array_equal(got0, exp)
+        monkeypatch.delenv("SADBM_DIRECT")
+        oa.reload_env()
+    # batches: frame groups (400-column frames, Wp = 400: 2-3 frames per 256-column block row), cropped batch views, a band
+    n, H, W = 7, win + 21, 400
+    Ls, Rs = zip(*[noise_pair(W + 13 * i + win, H, W, shift=min(2 + i, D - 1), binary=bool(i & 1)) for i in range(n)])
+    ctx = oa.Context(0)
+    out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, 0, ctx=ctx).cpu().numpy()
+    assert ctx.last_kernel().endswith("+direct")
+    for i in range(n):
+        assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), ("batch", i)
+    bl = torch.full((n, H + 2, W + 21), 99, dtype=torch.uint8, device="cuda"); br = torch.full((n, H + 2, W + 21), 77, dtype=torch.uint8, device="cuda")
+    bl[:, 1:1 + H, 5:5 + W] = dev(np.stack(Ls)); br[:, 1:1 + H, 5:5 + W] = dev(np.stack(Rs))
+    out = oa.compute_batch_device(bl[:, 1:1 + H, 5:5 + W], br[:, 1:1 + H, 5:5 + W], win, D, 0, ctx=ctx).cpu().numpy()
+    assert ctx.last_kernel().endswith("+direct")
+    for i in range(n):
+        assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), ("view", i)
+    r0, nb = 3, 11
+    i1 = min(r0 + nb + win - 1, H)
+    got = oa.compute_band_device(dev(Ls[0][r0:i1]), dev(Rs[0][r0:i1]), H, r0, nb, win, D, 0, ctx=ctx).cpu().numpy()
+    assert ctx.last_kernel().endswith("+direct")
+    assert np.array_equal(got, oracle.box(Ls[0], Rs[0], win, D)[r0:r0 + nb])

@@ -14,11 +14,14 @@ def test_baseline_configurations_get_the_documented_kernels():
     p = oa.plan(1080, 1920, 1, 64, 9, 64)                   # config 2
     assert p["kernel"] == "sad_strip_otf_kernel<9,4>" and p["FG"] == 2 and p["bx"] == 15 and p["tail"] > 0
     p = oa.plan(2160, 3840, 1, 32, 15, 128)                 # config 3
-    assert p["kernel"] == "sad_strip_kernel<15>" and p["threads"] == 512 and p["FG"] == 1 and p["bx"] == 15
+    assert p["kernel"] == "sad_strip_kernel<15>+direct" and p["threads"] == 512 and p["FG"] == 1 and p["bx"] == 15 and p["prep"] == 0 and p["scratch"] == 0
     p = oa.plan(4320, 7680, 1, 4, 21, 256)                  # config 4
-    assert p["kernel"] == "sad_strip_kernel<21>" and p["threads"] == 1024 and p["bx"] == 30
+    assert p["kernel"] == "sad_strip_kernel<21>+direct" and p["threads"] == 1024 and p["bx"] == 30 and p["prep"] == 0
     p = oa.plan(375, 1242, 1, 512, 7, 128)                  # config 5: 8 frames side by side fill 39 blocks of 256 columns
-    assert p["kernel"] == "sad_strip_kernel<7>" and p["FG"] == 8 and p["Wp"] == 1248 and p["bx"] == 39
+    assert p["kernel"] == "sad_strip_kernel<7>+direct" and p["FG"] == 8 and p["Wp"] == 1248 and p["bx"] == 39
+    p = oa.plan(2160, 3840, 3, 32, 15, 128)                 # BGR frames keep the prep pass (channel 0 -> padded planes)
+    assert p["kernel"] == "sad_strip_kernel<15>" and p["prep"] == 1 and p["scratch"] > 0
+    assert oa.plan(200, 300, 1, 8, 15, 128)["kernel"] == "sad_strip_kernel<15>"      # rows shorter than 384 bytes: planes (more than two edge rows possible)
     assert oa.plan(1080, 1920, 1, 1, 3, 30)["matcher"] == "quad"
     assert oa.plan(100, 100, 1, 1, 31, 30)["kernel"] == "sad_quad_lds_kernel<31,8>"       # 26 ... 49: the quad matcher (no strip instantiation)
     assert oa.plan(100, 100, 1, 1, 50, 30)["matcher"] == "wide"
@@ -27,7 +30,7 @@ def test_baseline_configurations_get_the_documented_kernels():
     assert oa.plan(7, 100, 1, 1, 7, 30)["matcher"] == "none"        # rows <= winSize: all-zero result, nothing to launch
     assert oa.plan(1080, 1920, 1, 1, 7, 30, oa.KERNEL_QUAD)["kernel"] == "sad_quad_lds_kernel<7,8>"
     assert oa.plan(1080, 1920, 1, 32, 7, 100)["kernel"] == "sad_strip_otf_kernel<7,8>"     # D % 16 != 0 up to 128: poisoned sums
-    assert oa.plan(1080, 1920, 1, 32, 7, 112)["kernel"] == "sad_strip_kernel<7>"
+    assert oa.plan(1080, 1920, 1, 32, 7, 112)["kernel"] == "sad_strip_kernel<7>+direct"
 
 
 def test_plan_rejects_what_the_calls_reject():
@@ -78,6 +81,8 @@ def test_strip_plans_cover_the_job():
         if p["matcher"] == "strip_otf":
             assert Deff <= 128 and p["lds"] <= 16 * 1024, what
             assert (p["prep"] == 0) == p["kernel"].endswith("+direct") and (p["prep"] == 1 or (ch == 1 and p["scratch"] == 0)), what
+        elif p["kernel"].endswith("+direct"):
+            assert ch == 1 and p["prep"] == 0 and p["scratch"] == 0 and cols >= 384 and p["threads"] >= 512 and p["lds"] <= 80 * 1024 * (2 if p["threads"] == 1024 else 1), what
         else:
             assert p["prep"] == 1 and p["scratch"] > 2 * (rows - 1) * cols * groups, what
     assert n_strip > 2000

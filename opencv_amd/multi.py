@@ -60,9 +60,11 @@ def disparity_row_bands(left_band, right_band, frame_rows, win, max_disp, rank, 
         return full[:frame_rows]
     # Ordering under RCCL: compute_band launches on torch's CURRENT stream (stereo.py passes torch.cuda.current_stream()); an
     # async collective first makes RCCL's stream wait for an event recorded on the current stream at the call, so a piece is
-    # gathered after the kernels that wrote it; the next compute_band writes OTHER rows of `send`; work.wait() at the end makes
-    # the current stream wait for every gather.  Nothing depends on timing.  (The piece aliases outs[rank]: the gather writes
-    # a rank's own rows onto themselves.)
+    # gathered after the kernels that wrote it; the next compute_band writes OTHER rows of `send`; work.wait() makes the current
+    # stream wait for the gather before the piece's rows are copied into the map.  Nothing depends on timing, and the collective
+    # sees only freshly allocated contiguous tensors: the piece goes through all_gather_into_tensor into a [world x rows, cols] slab
+    # of its own (the one-call form every RCCL user runs), and the slab is copied into the map's row ranges afterwards -- no list
+    # outputs, no output aliasing the input (round-2 advisor finding; one extra device copy of the map per frame).
     # Any other backend with device tensors (gloo rehearsals on a one-GPU box) exchanges each piece through host memory and
     # waits for it at once.  Handing gloo the DEVICE tensors hung in round 2 (two ranks sharing GPU 0, 540 x 7680 pieces of
     # the 8K frame); tools/gloo_piece_diag.py reproduced it once with stack dumps (profiles/r03_gloo_device_tensor_hang.txt):
@@ -73,10 +75,20 @@ def disparity_row_bands(left_band, right_band, frame_rows, win, max_disp, rank, 
     via_host = left_band.is_cuda and backend != "nccl"
     root = dst is None or dst == rank
     full = torch.zeros((world * per, cols), dtype=torch.uint8, device=left_band.device) if root else None
-    send = full[rank * per:(rank + 1) * per] if root else torch.zeros((per, cols), dtype=torch.uint8, device=left_band.device)
+    send = torch.zeros((per, cols), dtype=torch.uint8, device=left_band.device)
     sub_bands = max(1, min(int(sub_bands), per))
     sper = -(-per // sub_bands)
-    works = []
+    pending = []                                              # (work, slab or list of per-rank tensors, p0, p1)
+
+    def place(got, p0, p1):                                   # piece rows [p0, p1) of every rank's band -> the map
+        if root:
+            fv = full.view(world, per, cols)
+            if isinstance(got, list):
+                for r, g in enumerate(got):
+                    fv[r, p0:p1].copy_(g)
+            else:
+                fv[:, p0:p1].copy_(got.view(world, p1 - p0, cols))
+
     for s in range(sub_bands):
         p0, p1 = s * sper, min((s + 1) * sper, per)           # rows of the band slot, the same on every rank
         if p1 <= p0:
@@ -86,8 +98,7 @@ def disparity_row_bands(left_band, right_band, frame_rows, win, max_disp, rank, 
             i1 = min(s1 + win - 1, frame_rows)
             compute_band(left_band[s0 - r0:i1 - r0], right_band[s0 - r0:i1 - r0], frame_rows, s0, s1 - s0, win, max_disp, flags,
                          out=send[p0:p0 + (s1 - s0)])
-        piece = send[p0:p1]
-        outs = [full[r * per + p0:r * per + p1] for r in range(world)] if root else None   # contiguous row ranges of the map
+        piece = send[p0:p1]                                   # contiguous rows of `send`
         if via_host:
             hpiece = piece.cpu()
             houts = [torch.empty_like(hpiece) for _ in range(world)] if root else None
@@ -95,16 +106,21 @@ def disparity_row_bands(left_band, right_band, frame_rows, win, max_disp, rank, 
                 dist.all_gather(houts, hpiece, group=group)
             else:
                 dist.gather(hpiece, houts, dst=dst, group=group)
-            if root:
-                for o, h in zip(outs, houts):
-                    o.copy_(h)
+            place(houts, p0, p1)
             continue
         if dst is None:
-            works.append(dist.all_gather(outs, piece, group=group, async_op=True))
+            slab = torch.empty((world * (p1 - p0), cols), dtype=torch.uint8, device=left_band.device)   # rank-major, as the collective concatenates
+            work = dist.all_gather_into_tensor(slab, piece, group=group, async_op=True)
+            pending.append((work, slab, p0, p1))
         else:
-            works.append(dist.gather(piece, outs, dst=dst, group=group, async_op=True))
+            outs = [torch.empty((p1 - p0, cols), dtype=torch.uint8, device=left_band.device) for _ in range(world)] if root else None
+            work = dist.gather(piece, outs, dst=dst, group=group, async_op=True)
+            pending.append((work, outs, p0, p1))
         if not overlap:
-            works.pop().wait()
-    for w in works:
+            w, got, a, b = pending.pop()
+            w.wait()
+            place(got, a, b)
+    for w, got, a, b in pending:
         w.wait()
+        place(got, a, b)
     return full[:frame_rows] if root else None

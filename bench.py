@@ -360,6 +360,7 @@ def main():
             # kernel, kernel time (HIP events), its VALU fraction, and frames of the last step compared with the oracle
             for key, wl, n2, nver in (("frames_1080p_d128", "cfg2b_1080p_w9_d128", 64, 1), ("frames_1080p_d64", "cfg2_1080p_w9_d64", 64, 1),
                                       ("frames_1080p_w7_d30", "cfg2c_1080p_w7_d30", 64, 1), ("frames_384x288_w7_d30", "cfg1_tsukuba_size_w7_d30", 256, 4),
+                                      ("frames_384x288_w7_d30_x2048", "cfg1_tsukuba_size_w7_d30", 2048, 4),   # the same frames, a launch of 1.6 ms instead of 0.25
                                       ("cfg4_8k_w21_d256", "cfg4_8k_w21_d256", 4, 1), ("cfg5_kitti_w7_d128", "cfg5_kitti_w7_d128", 512, 16)):
                 if wl == args.workload:
                     continue

@@ -640,13 +640,17 @@ StripPlan plan_strip(int cus, bool host_inputs, int64_t pitchL, int64_t pitchR, 
     // (64-thread blocks with windows from 13 columns up: two staging units per lane, the direct variant spills 8-39 VGPRs;
     // 256-thread blocks with windows up to 13: the plane-reading variant stages the E words of L, which wins back a little more
     // than the prep pass costs on large jobs -- 64 x 1080p at 9x9 / D = 64: 1.865 + 0.086 ms against 1.969)
-    bool direct = use_strip && use_otf && channels == 1 && !host_inputs && env().direct != 0 && cols + 32 < 65000 &&
-                  !(otf_ng == 1 && win >= 13 && env().direct < 0) &&
-                  !(otf_ng >= 4 && win <= 13 && (long)n_pairs * nvalid * cols > 4000000L && env().direct < 0) &&
+    // Round 3: interleaved BGR frames -- what cv::imread hands the reference (SAD.cpp:65-66) -- are read in place too where the variant
+    // that gathers channel 0 itself is built (17-32 disparities, windows up to 8: strip_otf_kernels.hip): the reference's own call,
+    // one BGR pair at winSize 7 / DSR 30, is then one launch.
+    bool direct = use_strip && use_otf && !host_inputs && env().direct != 0 && cols + 32 < 65000 &&
+                  (channels == 1 ? (!(otf_ng == 1 && win >= 13 && env().direct < 0) &&
+                                    !(otf_ng >= 4 && win <= 13 && (long)n_pairs * nvalid * cols > 4000000L && env().direct < 0))
+                                 : pick_strip_otf_kernel(win, otf_ng, true, nullptr, channels) != nullptr) &&
                   (int64_t)need_rows * (pitchL > pitchR ? pitchL : pitchR) < 0x7ff00000LL;
     if (direct) {
         strip_frame_groups(cols, n_pairs, true, &FG, &Wp, &blocksg);
-        sk = pick_strip_otf_kernel(win, otf_ng, true, &otf_lds);
+        sk = pick_strip_otf_kernel(win, otf_ng, true, &otf_lds, channels);
     }
     // The staged kernel reads single-channel device images in place as well (round 3: no prep pass, no scratch planes; step traffic
     // 2.1-2.5x -> 1.1x the algorithmic 3 W H): its staging offsets are 32-bit from one base, so both batches must share a row
@@ -809,8 +813,8 @@ int run_pipeline(sadbm_ctx *ctx, const uint8_t *dL, int64_t pitchL, const uint8_
         q.pitch = pitch; q.W = cols; q.nvalid = nvalid; q.win = win; q.D = D;
         q.out = dOut; q.out_pitch = out_pitch; q.out_stride = pair_stride_out; q.flags = flags; q.dword_store = p.dword_store;
         q.dL = dL; q.dR = dR; q.in_stride = pair_stride_in; q.pitchL = (int)pitchL; q.pitchR = (int)pitchR;
-        q.extL = sp.direct ? (int)((int64_t)(need_rows - 1) * pitchL + cols) : 0;
-        q.extR = sp.direct ? (int)((int64_t)(need_rows - 1) * pitchR + cols) : 0;
+        q.extL = sp.direct ? (int)((int64_t)(need_rows - 1) * pitchL + (int64_t)cols * channels) : 0;
+        q.extR = sp.direct ? (int)((int64_t)(need_rows - 1) * pitchR + (int64_t)cols * channels) : 0;
         q.sdirect = sp.sdirect ? 1 : 0; q.nedge = sp.sdirect ? SDIRECT_NEDGE : 0; q.ll_delta = 0; q.loA = q.lenA = q.loB = q.lenB = 0;
         if (sp.sdirect) {
             q.Lrow0 = sd_base - strip::SDIRECT_BIAS;          // an address, never dereferenced below sd_base

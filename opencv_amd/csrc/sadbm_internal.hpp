@@ -78,7 +78,8 @@ quad_kernel_t pick_quad_lds_kernel(int win, int kc);     // sad_quad_lds_kernel<
 strip_kernel_t pick_strip_kernel(int win, int nslm);
 // strip_otf_kernels.hip: the on-the-fly form of the strip matcher, ng = 1, 2 or 4 disparity groups per block (64 ng threads); its dynamic LDS size
 // direct: the variant that reads the caller's single-channel images itself (SParams::dL ...) instead of padded planes
-strip_kernel_t pick_strip_otf_kernel(int win, int ng, bool direct, int *lds_bytes);
+// ch (direct only): 1, or 3 / 4 = interleaved colour frames whose channel 0 the kernel gathers itself (nullptr where that variant is not built)
+strip_kernel_t pick_strip_otf_kernel(int win, int ng, bool direct, int *lds_bytes, int ch = 1);
 // host copies of the strip kernel's compile-time geometry: staging passes per row image, dwords per row image
 void strip_geometry(int win, int nsl, int *pr, int *roww);
 

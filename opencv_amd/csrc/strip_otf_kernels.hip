@@ -145,9 +145,13 @@ __device__ __forceinline__ void strip_pass_otf(const uint32_t *pL, const uint32_
 // first row, past the last row's end -- is assembled byte by byte with zeros outside; everywhere else bytes beyond a
 // row's ends are the neighbouring rows' (or the pitch padding's) instead of zeros, and like the zeros of the padded
 // planes they only ever reach slots that never compete (k > column) and columns >= cols - win, which are written as 0.
-template <int WIN, int NG_, bool DIRECT>
+// CH (DIRECT only): channels of the caller's images; 3 / 4 = interleaved BGR / BGRA as cv::imread hands the reference (SAD.cpp:65-66): a
+// unit's 16 channel-0 bytes (SAD.cpp:19-20: Add[0]) are gathered from 48 / 64 bytes with v_perm_b32 when the unit is written to LDS
+// (round 3: the reference's own call -- one BGR pair -- then is ONE launch, no prep_plane_kernel, no scratch planes).
+template <int WIN, int NG_, bool DIRECT, int CH = 1>
 __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
 {
+    static_assert(CH == 1 || (DIRECT && (CH == 3 || CH == 4)), "colour frames are read in place only");
     using G = SG<WIN>;
     using O = OG<WIN, NG_, DIRECT>;
     constexpr int NV = G::NV;
@@ -220,21 +224,58 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
             if (f < nf) ubase[j] = (uright[j] ? p.dR : p.dL) + (int64_t)(pz * p.FG + f) * p.in_stride;   // else: no such frame, zeros
         }
     }
-    // 16 bytes of row `row`: at plane offset `off` (padded planes) or at column `off` of the frame at `b` (DIRECT)
-    auto fetch = [&](bool right, const uint8_t *b, uint32_t off, int row) -> u32x4u {
+    // 16 bytes of row `row`: at plane offset `off` (padded planes) or at column `off` of the frame at `b` (DIRECT); colour frames: the
+    // 16 CH bytes that hold them (Raw), channel 0 picked out by gather0 when the unit is written to LDS
+    struct Raw { u32x4u q[CH]; };
+    auto fetch = [&](bool right, const uint8_t *b, uint32_t off, int row) -> Raw {
+        Raw rw;
         if constexpr (!DIRECT) {
-            return *(const u32x4u *)(Lbase + (int64_t)row * p.pitch + off);
+            rw.q[0] = *(const u32x4u *)(Lbase + (int64_t)row * p.pitch + off);
         } else {
-            if (b == nullptr) return u32x4u{0, 0, 0, 0};
-            const int o = (right ? row * p.pitchR : row * p.pitchL) + (int)off;   // byte offset within the frame
+#pragma unroll
+            for (int j = 0; j < CH; ++j) rw.q[j] = u32x4u{0, 0, 0, 0};
+            if (b == nullptr) return rw;
+            const int o = (right ? row * p.pitchR : row * p.pitchL) + (int)off * CH;   // byte offset within the frame
             const int ext = right ? p.extR : p.extL;
-            if (o >= 0 && o + 16 <= ext) return *(const u32x4u *)(b + o);
-            uint32_t w[4] = {0, 0, 0, 0};                         // first row left of column 0, or the tail of the last rows
-            for (int i = 0; i < 16; ++i) {
-                const int oi = o + i;
-                if (oi >= 0 && oi < ext) w[i >> 2] |= (uint32_t)b[oi] << (8 * (i & 3));
+            if (o >= 0 && o + 16 * CH <= ext) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) rw.q[j] = *(const u32x4u *)(b + o + 16 * j);
+                return rw;
             }
-            return u32x4u{w[0], w[1], w[2], w[3]};
+            uint32_t w[4 * CH];                                   // first row left of column 0, or the tail of the last rows
+#pragma unroll
+            for (int i = 0; i < 4 * CH; ++i) w[i] = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {                        // pixel i of the unit: its channel-0 byte, where it would have been loaded
+                const int oi = o + i * CH;
+                if (oi >= 0 && oi < ext) w[(i * CH) >> 2] |= (uint32_t)b[oi] << (8 * ((i * CH) & 3));
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) rw.q[j] = u32x4u{w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]};
+        }
+        return rw;
+    };
+    // channel 0 of 16 interleaved pixels: BGR word j = bytes 12j, 12j+3, 12j+6, 12j+9 (dwords 3j .. 3j+2, two permutes), BGRA word j =
+    // byte 0 of dwords 4j .. 4j+3 (three permutes)
+    auto gather0 = [&](const Raw &rw) -> uint4 {
+        if constexpr (CH == 1) {
+            return make_uint4(rw.q[0].x, rw.q[0].y, rw.q[0].z, rw.q[0].w);
+        } else {
+            uint32_t d[4 * CH], o[4];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { d[4 * j] = rw.q[j].x; d[4 * j + 1] = rw.q[j].y; d[4 * j + 2] = rw.q[j].z; d[4 * j + 3] = rw.q[j].w; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (CH == 3) {
+                    const uint32_t t = __builtin_amdgcn_perm(d[3 * j + 1], d[3 * j], 0x0c060300u);       // S1 = d[3j]: bytes 0, 3; S0 = d[3j+1]: byte 2
+                    o[j] = __builtin_amdgcn_perm(d[3 * j + 2], t, 0x05020100u);                          // + byte 1 of d[3j+2]
+                } else {
+                    const uint32_t t1 = __builtin_amdgcn_perm(d[4 * j + 1], d[4 * j], 0x0c0c0400u);
+                    const uint32_t t2 = __builtin_amdgcn_perm(d[4 * j + 3], d[4 * j + 2], 0x04000c0cu);
+                    o[j] = t1 | t2;
+                }
+            }
+            return make_uint4(o[0], o[1], o[2], o[3]);
         }
     };
     // LV unit of this lane (lanes of the last wave): E words of L for column offset lva, strip lvs
@@ -258,23 +299,24 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
         lvo1 = (uint32_t)(P + lo0s[lva]); lvo2 = (uint32_t)(P + hi0s[lva]);
     }
     // row `row` of the plane -> row slot `slot` of buffer `buf`
-    struct Units { u32x4u w[UPL]; u32x4u v1, v2; };
+    struct Units { Raw w[UPL]; u32x4u v1, v2; };
     auto unit_load = [&](int row) -> Units {
         Units q;
 #pragma unroll
         for (int j = 0; j < UPL; ++j) {
-            q.w[j] = u32x4u{0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < CH; ++k) q.w[j].q[k] = u32x4u{0, 0, 0, 0};
             if (udst[j] >= 0) q.w[j] = fetch(uright[j], ubase[j], uoff[j], row);
         }
         if constexpr (O::LVS) {
-            if (lv_wave) { q.v1 = fetch(false, lvbase, lvo1, row); q.v2 = fetch(false, lvbase, lvo2, row); }
+            if (lv_wave) { q.v1 = fetch(false, lvbase, lvo1, row).q[0]; q.v2 = fetch(false, lvbase, lvo2, row).q[0]; }
         }
         return q;
     };
     auto unit_store = [&](const Units &q, int buf, int slot) {
 #pragma unroll
         for (int j = 0; j < UPL; ++j)
-            if (udst[j] >= 0) *(uint4 *)(rows + (buf * 2 + slot) * ROWW + udst[j]) = make_uint4(q.w[j].x, q.w[j].y, q.w[j].z, q.w[j].w);
+            if (udst[j] >= 0) *(uint4 *)(rows + (buf * 2 + slot) * ROWW + udst[j]) = gather0(q.w[j]);
         if constexpr (O::LVS) {
             if (lv_wave)
                 *(uint4 *)(rows + (buf * 2 + slot) * ROWW + lvdst) =
@@ -388,17 +430,25 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
 
 }  // namespace strip
 
-strip_kernel_t otf_part_1(int win, bool direct, int *lds_bytes);
-strip_kernel_t otf_part_2(int win, bool direct, int *lds_bytes);
-strip_kernel_t otf_part_4(int win, bool direct, int *lds_bytes);
-strip_kernel_t otf_part_8(int win, bool direct, int *lds_bytes);
+strip_kernel_t otf_part_1(int win, bool direct, int ch, int *lds_bytes);
+strip_kernel_t otf_part_2(int win, bool direct, int ch, int *lds_bytes);
+strip_kernel_t otf_part_4(int win, bool direct, int ch, int *lds_bytes);
+strip_kernel_t otf_part_8(int win, bool direct, int ch, int *lds_bytes);
 
 namespace {
 constexpr int PNG = SADBM_OTF_PART_NG;
-template <int WIN, bool DIRECT>
+// Colour frames in place: BGR, blocks of 128 threads (17-32 disparities: one staging unit per lane, whose three loads stay in flight
+// across a pass), windows up to 8 -- where it was measured faster than the prep pass (tools/bgr_ab.py, profiles/r03f_bgr_in_place.txt:
+// one 384x288 pair -17 %, 64 x 1080p 7x7 -4.8 %, 16 x 4K 8x8 -4.7 %).  Built and rejected: BGRA (four loads: 10 spilled VGPRs at
+// 7x7, +28 %), 256-thread blocks (9x9 / D = 64: 6 spills and no staged E words of L, +16 %; 12x12 +1.5 %), wider windows (6-30 spills).
+#ifndef SADBM_OTF_CH_WINS
+#define SADBM_OTF_CH_WINS 8
+#endif
+template <int WIN, bool DIRECT, int CH>
 static strip_kernel_t otf_entry()
 {
-    if constexpr (WIN >= 4 && strip::SG<WIN>::ok && strip::OG<WIN, PNG>::ok) return strip::sad_strip_otf_kernel<WIN, PNG, DIRECT>;
+    if constexpr (WIN >= 4 && strip::SG<WIN>::ok && strip::OG<WIN, PNG>::ok && (CH == 1 || (CH == 3 && PNG == 2 && WIN <= SADBM_OTF_CH_WINS)))
+        return strip::sad_strip_otf_kernel<WIN, PNG, DIRECT, CH>;
     else return nullptr;
 }
 template <int WIN, bool DIRECT>
@@ -408,11 +458,13 @@ static int otf_lds_one()
     else return 0;
 }
 template <int... I>
-strip_kernel_t otf_table(int win, bool direct, Seq<I...>)
+strip_kernel_t otf_table(int win, bool direct, int ch, Seq<I...>)
 {
-    static const strip_kernel_t t[] = { otf_entry<I + 1, false>()... };
-    static const strip_kernel_t td[] = { otf_entry<I + 1, true>()... };
-    return direct ? td[win - 1] : t[win - 1];
+    static const strip_kernel_t t[] = { otf_entry<I + 1, false, 1>()... };
+    static const strip_kernel_t td[] = { otf_entry<I + 1, true, 1>()... };
+    static const strip_kernel_t t3[] = { otf_entry<I + 1, true, 3>()... };
+    static const strip_kernel_t t4[] = { otf_entry<I + 1, true, 4>()... };
+    return !direct ? t[win - 1] : ch == 1 ? td[win - 1] : ch == 3 ? t3[win - 1] : ch == 4 ? t4[win - 1] : nullptr;
 }
 template <int... I>
 int otf_lds_table(int win, bool direct, Seq<I...>)
@@ -425,18 +477,19 @@ int otf_lds_table(int win, bool direct, Seq<I...>)
 
 #define SADBM_CAT2(a, b) a##b
 #define SADBM_CAT(a, b) SADBM_CAT2(a, b)
-strip_kernel_t SADBM_CAT(otf_part_, SADBM_OTF_PART_NG)(int win, bool direct, int *lds_bytes)
+strip_kernel_t SADBM_CAT(otf_part_, SADBM_OTF_PART_NG)(int win, bool direct, int ch, int *lds_bytes)
 {
     if (lds_bytes) *lds_bytes = otf_lds_table(win, direct, MakeSeq<MAXWIN>::type());
-    return otf_table(win, direct, MakeSeq<MAXWIN>::type());
+    return otf_table(win, direct, ch, MakeSeq<MAXWIN>::type());
 }
 
 #if SADBM_OTF_PART_NG == 2
-strip_kernel_t pick_strip_otf_kernel(int win, int ng, bool direct, int *lds_bytes)
+strip_kernel_t pick_strip_otf_kernel(int win, int ng, bool direct, int *lds_bytes, int ch)
 {
     if (win < 1 || win > MAXWIN) return nullptr;
-    return ng == 1 ? otf_part_1(win, direct, lds_bytes) : ng == 2 ? otf_part_2(win, direct, lds_bytes) : ng == 4 ? otf_part_4(win, direct, lds_bytes)
-         : ng == 8 ? otf_part_8(win, direct, lds_bytes) : nullptr;
+    if (!direct) ch = 1;                                      // the padded planes hold channel 0 already
+    return ng == 1 ? otf_part_1(win, direct, ch, lds_bytes) : ng == 2 ? otf_part_2(win, direct, ch, lds_bytes) : ng == 4 ? otf_part_4(win, direct, ch, lds_bytes)
+         : ng == 8 ? otf_part_8(win, direct, ch, lds_bytes) : nullptr;
 }
 #endif
 

@@ -82,10 +82,14 @@ def test_reference_parameters_whole_1080p_and_4k_frames():
         got = oa.compute_device(dev(L), dev(R), 7, D, oa.RAW_LOC, ctx=ctx).cpu().numpy()
         assert ctx.last_kernel() == "sad_strip_otf_kernel<7,2>+direct"
         assert_same(got, exp, "w7 D%d %dx%d" % (D, W, H))
-        L3 = np.stack([L, R, L], -1); R3 = np.stack([R, L, R], -1)       # BGR: channel 0 through the prep pass
+        L3 = np.stack([L, R, L], -1); R3 = np.stack([R, L, R], -1)       # BGR: channel 0 gathered by the matcher itself (round 3) ...
         got = oa.compute_device(dev(L3), dev(R3), 7, D, oa.RAW_LOC, ctx=ctx).cpu().numpy()
-        assert ctx.last_kernel() == "sad_strip_otf_kernel<7,2>"
+        assert ctx.last_kernel() == "sad_strip_otf_kernel<7,2>+direct"
         assert_same(got, exp, "w7 D%d %dx%d BGR" % (D, W, H))
+        L4 = np.stack([L, R, L, R], -1); R4 = np.stack([R, L, R, L], -1)  # ... BGRA: through the prep pass
+        got = oa.compute_device(dev(L4), dev(R4), 7, D, oa.RAW_LOC, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel() == "sad_strip_otf_kernel<7,2>"
+        assert_same(got, exp, "w7 D%d %dx%d BGRA" % (D, W, H))
 
 
 def test_config1_batch_of_256_and_config2_batch_whole_frames():

@@ -283,13 +283,16 @@ def test_direct_reads_with_frame_groups(W, monkeypatch):
             assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], win, D)), (W, win, D, i)
 
 
-def test_direct_is_not_used_for_colour_or_host_mapped_inputs():
+def test_direct_is_not_used_for_host_mapped_inputs_but_for_colour():
     from helpers import tsukuba_bgr
     L, R = tsukuba_bgr()
     ctx = oa.Context(0)
     exp = oracle.literal(np.ascontiguousarray(L[:, :, 0]), np.ascontiguousarray(R[:, :, 0]), 7, 30)
     assert np.array_equal(oa.compute_device(dev(L), dev(R), 7, 30, ctx=ctx).cpu().numpy(), exp)
-    assert ctx.last_kernel() == "sad_strip_otf_kernel<7,2>"               # BGR: channel 0 goes through the prep pass
+    assert ctx.last_kernel() == "sad_strip_otf_kernel<7,2>+direct"        # round 3: the reference's own call (a BGR pair, SAD.cpp:65-66,76) is one launch
+    assert np.array_equal(oa.compute_device(dev(L), dev(R), 15, 30, ctx=ctx).cpu().numpy(),
+                          oracle.box(np.ascontiguousarray(L[:, :, 0]), np.ascontiguousarray(R[:, :, 0]), 15, 30))
+    assert ctx.last_kernel() == "sad_strip_otf_kernel<15,2>"              # windows beyond 8: channel 0 goes through the prep pass
     assert np.array_equal(oa.get_disparity_host(L, R, 7, 30, ctx=ctx), exp)
     assert ctx.last_kernel() == "sad_strip_otf_kernel<7,2>"               # small host frames are read over PCIe: prep pass, once
     big = np.ascontiguousarray(np.tile(L[:, :, 0], (3, 3))); bigr = np.ascontiguousarray(np.tile(R[:, :, 0], (3, 3)))
@@ -404,3 +407,49 @@ def test_staged_kernel_reads_caller_images(win, D, monkeypatch):
     got = oa.compute_band_device(dev(Ls[0][r0:i1]), dev(Rs[0][r0:i1]), H, r0, nb, win, D, 0, ctx=ctx).cpu().numpy()
     assert ctx.last_kernel().endswith("+direct")
     assert np.array_equal(got, oracle.box(Ls[0], Rs[0], win, D)[r0:r0 + nb])
+
+
+@pytest.mark.parametrize("ch", [3])
+@pytest.mark.parametrize("win,D", [(7, 30), (7, 17), (8, 32), (5, 17), (6, 24)])
+def test_colour_frames_read_in_place(win, D, ch, monkeypatch):
+    """Round 3: interleaved BGR device frames (cv::imread's layout, SAD.cpp:65-66; the cost is channel 0's, SAD.cpp:19-20) are staged by
+    the on-the-fly kernel itself -- 48 bytes per unit, channel 0 gathered with v_perm_b32 -- at 17..32 disparities and windows up to 8
+    (the reference's winSize 7 / DSR 30): exact-size allocations (byte-wise edge path), planes that differ in every channel, ROI views
+    with different pitches, frame groups of a batch, a band, binary dots; equal to the oracle on plane 0 and to the prep-pass path.
+    Frames narrower than 17 columns search fewer than 17 disparities (64-thread blocks): prep pass."""
+    import torch
+    rng = np.random.default_rng(win * 100 + D + ch)
+    p0 = lambda a: np.ascontiguousarray(a[..., 0])
+    for (H, W, binary) in ((win + 3, 300, False), (40, 517, True), (win + 2, 9 + win, False), (win + 8, 256, False), (win + 1, 1000, True), (288, 384, False)):
+        L, R = noise_pair(H * 7 + W + D, H, W, shift=min(5, W - 1), binary=binary, ch=ch)
+        exp = oracle.box(p0(L), p0(R), win, D)
+        ctx = oa.Context(0)
+        got = oa.compute_device(dev(L), dev(R), win, D, 0, ctx=ctx).cpu().numpy()                 # exact-size allocations
+        in_place = min(D, W) > 16
+        assert ctx.last_kernel() == strip_kernel_name(win, D, cols=W) + ("+direct" if in_place else ""), ctx.last_kernel()
+        assert np.array_equal(got, exp), (H, W, "exact", np.argwhere(got != exp)[:4])
+        bl = torch.from_numpy(rng.integers(0, 256, size=(H, W + 37, ch), dtype=np.uint8)).cuda()
+        br = torch.from_numpy(rng.integers(0, 256, size=(H + 3, W + 80, ch), dtype=np.uint8)).cuda()
+        bl[:, 5:5 + W] = dev(L); br[2:2 + H, 41:41 + W] = dev(R)
+        got = oa.compute_device(bl[:, 5:5 + W], br[2:2 + H, 41:41 + W], win, D, 0, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel().endswith("+direct") == in_place
+        assert np.array_equal(got, exp), (H, W, "roi")
+        monkeypatch.setenv("SADBM_DIRECT", "0")
+        oa.reload_env()
+        got0 = oa.compute_device(dev(L), dev(R), win, D, 0, ctx=ctx).cpu().numpy()
+        assert ctx.last_kernel() == strip_kernel_name(win, D, cols=W)
+        assert np.array_equal(got0, exp)
+        monkeypatch.delenv("SADBM_DIRECT")
+        oa.reload_env()
+    n, H, W = 7, 45, 203
+    Ls, Rs = zip(*[noise_pair(30 + i + win, H, W, shift=min(D - 1, 3 + i), binary=bool(i & 1), ch=ch) for i in range(n)])
+    ctx = oa.Context(0)
+    out = oa.compute_batch_device(dev(np.stack(Ls)), dev(np.stack(Rs)), win, D, 0, ctx=ctx).cpu().numpy()
+    assert ctx.last_kernel().endswith("+direct")
+    for i in range(n):
+        assert np.array_equal(out[i], oracle.box(p0(Ls[i]), p0(Rs[i]), win, D)), i
+    r0, nb = 7, 12
+    i1 = min(r0 + nb + win - 1, H)
+    got = oa.compute_band_device(dev(Ls[0][r0:i1]), dev(Rs[0][r0:i1]), H, r0, nb, win, D, 0, ctx=ctx).cpu().numpy()
+    assert ctx.last_kernel().endswith("+direct")
+    assert np.array_equal(got, oracle.box(p0(Ls[0]), p0(Rs[0]), win, D)[r0:r0 + nb])

@@ -8,7 +8,7 @@ import opencv_amd as oa
 
 def test_baseline_configurations_get_the_documented_kernels():
     p = oa.plan(288, 384, 3, 1, 7, 30)                      # the reference's own call: BGR pair, winSize 7, DSR 30 (SAD.cpp:9,11,65-66)
-    assert p["kernel"] == "sad_strip_otf_kernel<7,2>" and p["prep"] == 1 and p["threads"] == 128
+    assert p["kernel"] == "sad_strip_otf_kernel<7,2>+direct" and p["prep"] == 0 and p["scratch"] == 0 and p["threads"] == 128   # round 3: one launch
     p = oa.plan(288, 384, 1, 256, 7, 30)                    # config 1 as a batch of grey frames: read in place, two frames per group
     assert p["kernel"] == "sad_strip_otf_kernel<7,2>+direct" and p["scratch"] == 0 and p["FG"] == 2 and p["bx"] == 3
     p = oa.plan(1080, 1920, 1, 64, 9, 64)                   # config 2
@@ -80,7 +80,8 @@ def test_strip_plans_cover_the_job():
         assert 16 * (p["threads"] // 64) >= Deff, what                                   # the block's disparity slots cover the search
         if p["matcher"] == "strip_otf":
             assert Deff <= 128 and p["lds"] <= 16 * 1024, what
-            assert (p["prep"] == 0) == p["kernel"].endswith("+direct") and (p["prep"] == 1 or (ch == 1 and p["scratch"] == 0)), what
+            assert (p["prep"] == 0) == p["kernel"].endswith("+direct") and (p["prep"] == 1 or p["scratch"] == 0), what
+            assert p["prep"] == 1 or ch == 1 or (ch == 3 and p["threads"] == 128 and win <= 8), what          # BGR in place: where that variant is built
         elif p["kernel"].endswith("+direct"):
             assert ch == 1 and p["prep"] == 0 and p["scratch"] == 0 and cols >= 384 and p["threads"] >= 512 and p["lds"] <= 80 * 1024 * (2 if p["threads"] == 1024 else 1), what
         else:

@@ -24,8 +24,8 @@ for line in out.splitlines():
 for name, r in rows.items():
     m = re.search(r"sad_strip_kernelILi(\d+)ELi(\d+)E", name)
     if not m:
-        m = re.search(r"sad_strip_otf_kernelILi(\d+)ELi(\d+)ELb(\d)E", name)
+        m = re.search(r"sad_strip_otf_kernelILi(\d+)ELi(\d+)ELb(\d)ELi(\d)E", name)
         if m:
-            print(f"otf<{m.group(1)},{m.group(2)},{m.group(3)}> vgpr {r.get('VGPRs')} sgpr {r.get('SGPRs')} scratch {r.get('ScratchSize')} sgpr_spill {r.get('SGPRs Spill')} vgpr_spill {r.get('VGPRs Spill')} occ {r.get('Occupancy')}")
+            print(f"otf<{m.group(1)},{m.group(2)},{m.group(3)},{m.group(4)}> vgpr {r.get('VGPRs')} sgpr {r.get('SGPRs')} scratch {r.get('ScratchSize')} sgpr_spill {r.get('SGPRs Spill')} vgpr_spill {r.get('VGPRs Spill')} occ {r.get('Occupancy')}")
         continue
     print(f"strip<{m.group(1)},{m.group(2)}> vgpr {r.get('VGPRs')} sgpr {r.get('SGPRs')} scratch {r.get('ScratchSize')} sgpr_spill {r.get('SGPRs Spill')} vgpr_spill {r.get('VGPRs Spill')} occ {r.get('Occupancy')}")

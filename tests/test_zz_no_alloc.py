@@ -17,7 +17,9 @@ def test_static_entry_matches_compute_device_twice_second_smaller():
     import torch
     lib = oa.load_library()
     ctx = oa.Context(0)
-    for (H, W, win, D, ch) in ((700, 1300, 15, 128, 1), (181, 407, 7, 30, 3), (150, 300, 60, 100, 1)):   # the last one: sad_wide_kernel
+    # grey frames and BGR frames at the reference's parameters are read in place (no scratch at all); the static scratch planes are
+    # what BGR frames under the staged kernel (third case), BGRA frames and the wide-window matcher (last case) go through
+    for (H, W, win, D, ch) in ((700, 1300, 15, 128, 1), (181, 407, 7, 30, 3), (420, 900, 15, 128, 3), (300, 640, 9, 64, 4), (150, 300, 60, 100, 1)):
         L, R = noise_pair(H + W, H, W, shift=5, ch=ch)
         dL, dR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
         ref = oa.compute_device(dL, dR, win, D, ctx=ctx)

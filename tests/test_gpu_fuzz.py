@@ -88,3 +88,48 @@ def test_very_wide_frame_and_many_tiny_frames():
     assert ctx.last_kernel() == "sad_strip_kernel<4>"            # 4-wide windows keep the staged form from 17 disparities up
     for i in range(n):
         assert np.array_equal(out[i], oracle.box(Ls[i], Rs[i], 4, 48)), i
+
+
+@pytest.mark.parametrize("chunk", range(12))
+def test_random_views_read_in_place_match_oracle(chunk):
+    """Round 3: the matchers read device frames in place (grey frames under both strip kernels, BGR under the on-the-fly kernel).  Random
+    views of larger buffers -- the frame at the very start or end of its allocation or somewhere inside, any row pitch, frames of a batch
+    any distance apart, bands of a taller frame -- must give the oracle's bits and leave everything round the output untouched: the
+    byte-wise edge rows, the frame-group arithmetic and the 32-bit offsets of the staged kernel's direct form are all in play."""
+    import torch
+    rng = np.random.default_rng(4242 + chunk)
+    for case in range(16):
+        win = int(rng.integers(4, 26))
+        D = int(rng.choice([17, 30, 32, 48, 64, 65, 96, 128, 130, 200, 256]))
+        W = int(rng.choice([384, 385, 400, 511, 512, 640, int(rng.integers(384, 1400))]))
+        H = int(rng.integers(win + 1, win + 60))
+        pairs = int(rng.choice([1, 1, 2, 3, 6]))
+        ch = 3 if (D <= 32 and win <= 8 and rng.random() < 0.5) else 1
+        top, left = int(rng.choice([0, 0, 1, 5])), int(rng.choice([0, 0, 3, 16, 41]))
+        bottom, right = int(rng.choice([0, 0, 2])), int(rng.choice([0, 0, 7, 64]))
+        gap = int(rng.choice([0, 0, 1, 3]))                      # extra rows between the frames of the batch
+        Ls, Rs = zip(*[noise_pair(9 * case + i + 1000 * chunk, H, W, shift=1 + (i + case) % 9, binary=(case % 5 == 4), ch=ch) for i in range(pairs)])
+        shp = (pairs, top + H + bottom + gap, left + W + right) + ((ch,) if ch > 1 else ())
+        bl = torch.from_numpy(rng.integers(0, 256, size=shp, dtype=np.uint8)).cuda()
+        br = torch.from_numpy(rng.integers(0, 256, size=shp, dtype=np.uint8)).cuda()
+        vl, vr = bl[:, top:top + H, left:left + W], br[:, top:top + H, left:left + W]
+        vl.copy_(torch.from_numpy(np.stack(Ls)).cuda()); vr.copy_(torch.from_numpy(np.stack(Rs)).cuda())
+        p0 = (lambda a: np.ascontiguousarray(a[..., 0])) if ch > 1 else (lambda a: a)
+        exps = [oracle.box(p0(Ls[i]), p0(Rs[i]), win, D) for i in range(pairs)]
+        ctx = oa.Context(0)
+        obuf = torch.full((pairs, H + 2, W + 6), 0xAB, dtype=torch.uint8, device="cuda")
+        out = obuf[:, 1:1 + H, 3:3 + W]
+        oa.compute_batch_device(vl, vr, win, D, 0, out=out, ctx=ctx)
+        got = obuf.cpu().numpy()
+        what = (chunk, case, win, D, H, W, pairs, ch, top, left, bottom, right, gap, ctx.last_kernel())
+        assert ctx.last_kernel().endswith("+direct") or (win == 4 and D <= 64), what      # 4-wide windows: quad matcher / 256-thread staged blocks keep the planes
+        for i in range(pairs):
+            bad = np.argwhere(got[i, 1:1 + H, 3:3 + W] != exps[i])
+            assert bad.size == 0, (what, i, len(bad), bad[:5])
+        assert (got[:, 0] == 0xAB).all() and (got[:, 1 + H:] == 0xAB).all() and (got[:, :, :3] == 0xAB).all() and (got[:, :, 3 + W:] == 0xAB).all(), what
+        # a band of the first frame (what one GPU of a row-band split computes), read in place as well
+        if H > win + 6:
+            r0 = int(rng.integers(0, H - win - 3)); nb = int(rng.integers(1, H - r0 + 1))
+            i1 = min(r0 + nb + win - 1, H)
+            gb = oa.compute_band_device(vl[0, r0:i1], vr[0, r0:i1], H, r0, nb, win, D, 0, ctx=ctx).cpu().numpy()
+            assert np.array_equal(gb, exps[0][r0:r0 + nb]), (what, "band", r0, nb)

@@ -453,3 +453,29 @@ def test_colour_frames_read_in_place(win, D, ch, monkeypatch):
     got = oa.compute_band_device(dev(Ls[0][r0:i1]), dev(Rs[0][r0:i1]), H, r0, nb, win, D, 0, ctx=ctx).cpu().numpy()
     assert ctx.last_kernel().endswith("+direct")
     assert np.array_equal(got, oracle.box(p0(Ls[0]), p0(Rs[0]), win, D)[r0:r0 + nb])
+
+
+def test_profile_events_report_no_prep_time_when_no_prep_pass_runs():
+    """sadbm_profile_begin / _end (HIP events round the kernels): launches that read the frames in place report 0 for the prep pass (two events
+    recorded back to back would read as ~5 us), launches through the prep pass a positive time; more launches than asked for are not counted."""
+    import torch
+    ctx = oa.Context(0)
+    L, R = noise_pair(3, 300, 640, shift=7)
+    dL, dR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    L4, R4 = noise_pair(4, 300, 640, shift=7, ch=4)
+    dL4, dR4 = torch.from_numpy(L4).cuda(), torch.from_numpy(R4).cuda()
+    ctx.profile_begin(4)
+    for _ in range(6):
+        oa.compute_device(dL, dR, 7, 30, ctx=ctx)
+    torch.cuda.synchronize()
+    n, m, p = ctx.profile_end()
+    assert ctx.last_kernel().endswith("+direct") and n == 4 and m > 0 and p == 0
+    ctx.profile_begin(4)
+    for _ in range(3):
+        oa.compute_device(dL4, dR4, 7, 30, ctx=ctx)
+    oa.compute_device(dL, dR, 7, 30, ctx=ctx)
+    torch.cuda.synchronize()
+    n, m, p = ctx.profile_end()
+    assert n == 4 and m > 0 and p > 0
+    ctx.profile_begin(2)                                       # nothing launched: zeros
+    assert ctx.profile_end() == (0, 0.0, 0.0)

@@ -43,6 +43,9 @@ void strip_geometry_table(int win, int nsl, int *pr, int *roww, Seq<I...>)
 template <int WIN, int NSLM>
 static strip_kernel_t strip_entry()
 {
+#ifdef SADBM_ONLY_WIN
+    if constexpr (WIN != SADBM_ONLY_WIN) return nullptr; else                                       // experiment builds: one window
+#endif
     if constexpr (WIN >= 4 && WIN <= SADBM_STRIP_WINS && strip::SG<WIN>::ok) return strip::sad_strip_kernel<WIN, NSLM>;
     else return nullptr;
 }

@@ -17,6 +17,8 @@ for (W, H, pairs, win, D) in jobs:
     nv = H - win
     line = "%4dx%4d x%3d w%2d D%3d:" % (W, H, pairs, win, D)
     tys = [0, 64, 128, 256, 512] + sorted({(nv + k - 1) // k for k in (1, 2, 3, 4, 6)}, reverse=True) + [0]
+    if pairs <= 2:                                             # single frames: short bands
+        tys = [0, 6, 8, 12, 16, 20, 24, 32, 40, 48, 64, 96, 128, 0]
     for ty in tys:
         os.environ["SADBM_STRIP_TY"] = str(ty)
         oa.reload_env()
@@ -24,8 +26,9 @@ for (W, H, pairs, win, D) in jobs:
         for _ in range(2):
             oa.compute_batch_device(dL, dR, win, D, 0, out=dO, ctx=ctx)
         torch.cuda.synchronize()
-        ctx.profile_begin(5)
-        for _ in range(5):
+        reps = 5 if pairs > 2 else 30
+        ctx.profile_begin(reps)
+        for _ in range(reps):
             oa.compute_batch_device(dL, dR, win, D, 0, out=dO, ctx=ctx)
         torch.cuda.synchronize()
         n, m, p = ctx.profile_end()

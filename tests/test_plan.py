@@ -87,3 +87,42 @@ def test_strip_plans_cover_the_job():
         else:
             assert p["prep"] == 1 and p["scratch"] > 2 * (rows - 1) * cols * groups, what
     assert n_strip > 2000
+
+
+def test_bench_traffic_entries_describe_the_kernels_that_run():
+    """bench.py takes roofline.traffic from bench_traffic.json, keyed by (workload, kernel, pairs per launch).  Every workload's CURRENT
+    kernel (what the launch policy picks today) must have an entry -- a renamed or re-routed kernel fails here, on CPU, not in the
+    round-end bench -- and every entry from round 2 on must still be what its profiles/ file says: the file exists, holds a PMC
+    section of that kernel, and 2 x FETCH_SIZE + WRITE_SIZE of that section (KB; gfx950 tallies 16-byte reads at half size) is the entry."""
+    import json
+    import os
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    with open(os.path.join(root, "bench_traffic.json")) as f:
+        tj = json.load(f)
+    for name, (W, H, win, D, _seed, _bg, _fg, pairs) in bench.WORKLOADS.items():
+        if name.startswith("wide_"):
+            continue                                           # profiling-only workload (SADBM_BENCH_ALLOW_NO_TRAFFIC)
+        key = "%s|%s|pairs=%d" % (name, oa.plan(H, W, 1, pairs, win, D)["kernel"], pairs)
+        assert key in tj, key
+    checked = 0
+    for key, ent in tj.items():
+        m = re.match(r"(profiles/r0[2-9]\S+\.txt)", ent["source"])
+        if not m:
+            continue                                           # round-1 entries: files since superseded, kernels no longer the default
+        path = os.path.join(root, m.group(1))
+        assert os.path.exists(path), (key, path)
+        kernel = key.split("|")[1].replace("+direct", "")
+        base = kernel.split("<")[0] + "<" + kernel.split("<")[1].rstrip(">").replace(",", ", ")    # rocprofv3 prints "<7, 2, true>", "<15, 24>"
+        lines = open(path).read().splitlines()
+        starts = [i for i, l in enumerate(lines) if l.startswith(base) and "calls=" not in l]
+        assert starts, (key, base, path)
+        sect = lines[starts[0] + 1:]
+        fetch = next(float(re.search(r"mean=([0-9.e+]+)", l).group(1)) for l in sect if l.strip().startswith("FETCH_SIZE"))
+        write = next(float(re.search(r"mean=([0-9.e+]+)", l).group(1)) for l in sect if l.strip().startswith("WRITE_SIZE"))
+        assert abs((2 * fetch + write) * 1024 - ent["hbm_bytes_per_launch"]) <= 0.002 * ent["hbm_bytes_per_launch"], (key, fetch, write)
+        checked += 1
+    assert checked >= 9

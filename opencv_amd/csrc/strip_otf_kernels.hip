@@ -15,6 +15,9 @@
 // (class, group) combinations are dealt to the waves four at a time (combination q = 4 wave + kgl: group q mod NG, class
 // q / NG -- one wave of 4 classes at NG = 1, two waves of 2 classes x 2 groups at NG = 2, one class per wave at NG = 4); the
 // one or two staging units per lane and step are prefetched round the ADD and SUB passes.
+#ifndef SADBM_OTF_PRIO_PHASE
+#define SADBM_OTF_PRIO_PHASE (NG_ >= 2 ? 5 : 0)             // sad_strip_otf_kernel: issue priority by phase of the step (see the march loop)
+#endif
 #include "sadbm_internal.hpp"
 
 #ifndef SADBM_OTF_PART_NG
@@ -392,10 +395,15 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
         if (more) wn = unit_load(yb + r + 1);
         if (active) strip_pass_otf<WIN, NG_, DIRECT, false>(tL + bo, tR + bo, V, E);
         if (more) unit_store(wn, (r + 1) & 1, 0);
+        if (SADBM_OTF_PRIO_PHASE == 5) __builtin_amdgcn_s_setprio(0);
         if (more_old) wo = unit_load(yb + r + 1 - WIN);
         if (active && r >= WIN) strip_pass_otf<WIN, NG_, DIRECT, true>(tL + bo + ROWW, tR + bo + ROWW, V, E);
         if (more_old) unit_store(wo, (r + 1) & 1, 1);
 
+        // Issue priority by phase (s_setprio): the SUB pass at the default, the ADD pass and the key phase raised -- with 4-16 small blocks per
+        // CU in different phases, -2.7 ... -5.1 % on every block size from two waves up (profiles/r03o_issue_priority.txt; only the ADD pass
+        // or only the key phase raised: -0.4 ... -2 %; passes raised and key phase at the default, the staged kernel's rule: +1.5 ... +2.9 %)
+        if (SADBM_OTF_PRIO_PHASE == 5) __builtin_amdgcn_s_setprio(1);
         if (emit && wave_active) {
             uint32_t pub[4] = {KEY_MAX, KEY_MAX, KEY_MAX, KEY_MAX};
             if (mask_d)          strip_emit<WIN, EM_MASK, false>(V, E, active, kgl, ec, pub);

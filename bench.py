@@ -369,9 +369,15 @@ def main():
                 l2 = torch.from_numpy(np.stack([f[0] for f in fr])).to(dev)
                 r2 = torch.from_numpy(np.stack([f[1] for f in fr])).to(dev)
                 o2 = torch.empty((n2, h2, w2), dtype=torch.uint8, device=dev)
-                for _ in range(3):
-                    oa.compute_batch_device(l2, r2, win2, d2, 0, out=o2, ctx=ctx)
-                torch.cuda.synchronize()
+                # untimed warm-up: at least 3 launches and 0.1 s -- the oracle checks between the legs leave the GPU idle for seconds, and
+                # three launches of a 1 ms kernel do not bring the clocks back (the leg then reads 8-10 % low)
+                t_w = time.perf_counter()
+                while True:
+                    for _ in range(3):
+                        oa.compute_batch_device(l2, r2, win2, d2, 0, out=o2, ctx=ctx)
+                    torch.cuda.synchronize()
+                    if time.perf_counter() - t_w > 0.1:
+                        break
                 ctx.profile_begin(10)
                 t0 = time.perf_counter()
                 for _ in range(10):

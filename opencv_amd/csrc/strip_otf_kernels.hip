@@ -18,6 +18,7 @@
 #ifndef SADBM_OTF_PRIO_PHASE
 #define SADBM_OTF_PRIO_PHASE (NG_ >= 2 ? 5 : 0)             // sad_strip_otf_kernel: issue priority by phase of the step (see the march loop)
 #endif
+#include <type_traits>
 #include "sadbm_internal.hpp"
 
 #ifndef SADBM_OTF_PART_NG
@@ -48,6 +49,33 @@ struct OG {
         for (int b = 0; b < G::nh(a); ++b) s |= (uint32_t)(4 + bh(a) + b) << (8 * n++);
         for (; n < 4; ++n) s |= 0x0cu << (8 * n);
         return s;
+    }
+    // E words whose bytes are ONE run inside one aligned word need no compaction: both operands masked in place give the same SAD, and
+    // v_and_b32 (VOP2) issues faster than v_perm_b32 (profiles/r01_ubench_valu_mix_vs_occupancy.txt).  Worth it since the issue priorities of
+    // round 3 left these kernels bounded by their instruction stream alone.
+#ifndef SADBM_OTF_ANDMASK
+#define SADBM_OTF_ANDMASK 1
+#endif
+    static constexpr bool single(int a) { return SADBM_OTF_ANDMASK && G::ne(a) > 0 && (G::nl(a) == 0 || G::nh(a) == 0); }
+    static constexpr uint32_t amask(int a)
+    {
+        const int b0 = G::nl(a) ? bl(a) : bh(a);
+        uint32_t m = 0;
+        for (int b = 0; b < G::ne(a); ++b) m |= 0xFFu << (8 * (b0 + b));
+        return m;
+    }
+    static constexpr uint32_t sel_inplace(int a)                 // v_perm_b32(x, x, sel) == x & amask(a): for the lanes that pack staged E words of L (LVS)
+    {
+        uint32_t s = 0;
+        for (int b = 0; b < 4; ++b) s |= (((amask(a) >> (8 * b)) & 0xFFu) ? (uint32_t)b : 0x0cu) << (8 * b);
+        return s;
+    }
+    template <int A>
+    static __device__ __forceinline__ uint32_t eword(uint32_t whi, uint32_t wlo)
+    {
+        if constexpr (G::ne(A) == 0) return 0u;
+        else if constexpr (single(A)) return wlo & amask(A);     // wl(A) is the run's word whichever run it is
+        else return __builtin_amdgcn_perm(whi, wlo, sel(A));
     }
     static constexpr bool run_ok(int a) { return (G::nl(a) == 0 || bl(a) + G::nl(a) <= 4) && (G::nh(a) == 0 || bh(a) + G::nh(a) <= 4); }
     static constexpr int wmax1(int a) { return G::ne(a) ? (wl(a) > wh(a) ? wl(a) : wh(a)) : 0; }
@@ -110,10 +138,9 @@ __device__ __forceinline__ void strip_pass_otf(const uint32_t *pL, const uint32_
             }
     }
     // ---- E: leftover bytes, packed here; two column offsets per register (a = 2p low half, 2p+1 high half) ----
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        constexpr int A0[2] = {0, 2}, A1[2] = {1, 3};
-        const int a0 = A0[p], a1 = A1[p];
+    auto e_pair = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int a0 = 2 * p, a1 = 2 * p + 1;
         uint32_t l0[4] = {0, 0, 0, 0}, l1[4] = {0, 0, 0, 0}, r0[7], r1[7];
         if constexpr (O::LVS) {
             if (G::ne(a0) > 0) lds128(pL + O::OFF_LV + a0 * (4 * NS), l0);
@@ -121,14 +148,14 @@ __device__ __forceinline__ void strip_pass_otf(const uint32_t *pL, const uint32_
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                l0[i] = G::ne(a0) ? __builtin_amdgcn_perm(lw[i + O::wh(a0)], lw[i + O::wl(a0)], O::sel(a0)) : 0u;
-                l1[i] = G::ne(a1) ? __builtin_amdgcn_perm(lw[i + O::wh(a1)], lw[i + O::wl(a1)], O::sel(a1)) : 0u;
+                l0[i] = O::template eword<a0>(lw[i + O::wh(a0)], lw[i + O::wl(a0)]);
+                l1[i] = O::template eword<a1>(lw[i + O::wh(a1)], lw[i + O::wl(a1)]);
             }
         }
 #pragma unroll
         for (int d = 0; d < 7; ++d) {                            // d = i - t + 3
-            r0[d] = G::ne(a0) ? __builtin_amdgcn_perm(rw[d + 1 + O::wh(a0)], rw[d + 1 + O::wl(a0)], O::sel(a0)) : 0u;
-            r1[d] = G::ne(a1) ? __builtin_amdgcn_perm(rw[d + 1 + O::wh(a1)], rw[d + 1 + O::wl(a1)], O::sel(a1)) : 0u;
+            r0[d] = O::template eword<a0>(rw[d + 1 + O::wh(a0)], rw[d + 1 + O::wl(a0)]);
+            r1[d] = O::template eword<a1>(rw[d + 1 + O::wh(a1)], rw[d + 1 + O::wl(a1)]);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -140,7 +167,9 @@ __device__ __forceinline__ void strip_pass_otf(const uint32_t *pL, const uint32_
                 if constexpr (!SUB) E[t][i][p] = e;
                 else E[t][i][p] -= e;
             }
-    }
+    };
+    e_pair(std::integral_constant<int, 0>());
+    e_pair(std::integral_constant<int, 1>());
 }
 
 // DIRECT: the staging units are read from the caller's single-channel images themselves (no prep_plane_kernel pass, no
@@ -286,10 +315,15 @@ __global__ void __launch_bounds__(64 * NG_, 4) sad_strip_otf_kernel(SParams p)
     uint32_t lvo1 = 0, lvo2 = 0, lvsel = 0; int lvdst = 0; const uint8_t *lvbase = nullptr;
     if constexpr (O::LVS) {
         const int lva = lane >> 4, lvs = lane & 15;
-        const uint32_t sels[4] = {G::sel(0), G::sel(1), G::sel(2), G::sel(3)};
+        // two-run E words: the staged kernel's packing (unaligned windows at the runs, compacted by G::sel); one-run E words stay in place in their
+        // aligned word, masked (the compute lanes mask their R partners the same way: OG::eword)
+        const uint32_t sels[4] = {O::single(0) ? O::sel_inplace(0) : G::sel(0), O::single(1) ? O::sel_inplace(1) : G::sel(1),
+                                  O::single(2) ? O::sel_inplace(2) : G::sel(2), O::single(3) ? O::sel_inplace(3) : G::sel(3)};
         // a run that is empty reads where the other one does
-        const int lo0s[4] = {G::nl(0) ? G::lo0(0) : G::hi0(0), G::nl(1) ? G::lo0(1) : G::hi0(1), G::nl(2) ? G::lo0(2) : G::hi0(2), G::nl(3) ? G::lo0(3) : G::hi0(3)};
-        const int hi0s[4] = {G::nh(0) ? G::hi0(0) : lo0s[0], G::nh(1) ? G::hi0(1) : lo0s[1], G::nh(2) ? G::hi0(2) : lo0s[2], G::nh(3) ? G::hi0(3) : lo0s[3]};
+        const int lo0r[4] = {G::nl(0) ? G::lo0(0) : G::hi0(0), G::nl(1) ? G::lo0(1) : G::hi0(1), G::nl(2) ? G::lo0(2) : G::hi0(2), G::nl(3) ? G::lo0(3) : G::hi0(3)};
+        const int lo0s[4] = {O::single(0) ? 4 * O::wl(0) : lo0r[0], O::single(1) ? 4 * O::wl(1) : lo0r[1], O::single(2) ? 4 * O::wl(2) : lo0r[2], O::single(3) ? 4 * O::wl(3) : lo0r[3]};
+        const int hi0s[4] = {G::nh(0) && !O::single(0) ? G::hi0(0) : lo0s[0], G::nh(1) && !O::single(1) ? G::hi0(1) : lo0s[1],
+                             G::nh(2) && !O::single(2) ? G::hi0(2) : lo0s[2], G::nh(3) && !O::single(3) ? G::hi0(3) : lo0s[3]};
         int P = XB + 16 * lvs;
         lvsel = sels[lva]; lvdst = O::OFF_LV + lva * (4 * NS) + 4 * lvs;
         if constexpr (DIRECT) {

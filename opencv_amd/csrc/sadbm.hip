@@ -638,15 +638,16 @@ StripPlan plan_strip(int cus, bool host_inputs, int64_t pitchL, int64_t pitchR, 
     // launch less per call), with the same frame groups (tools/fg_stride.py, profiles/r02f_otf_direct_frame_groups.txt: 64 x
     // 1080p at 7x7 / D = 30: 0.98 ms against 0.955 + 0.085).  Not for inputs the GPU reads over PCIe (the host API's zero-copy
     // staging): the matcher reads every byte ~5 times.
-    // (64-thread blocks with windows from 13 columns up: two staging units per lane, the direct variant spills 8-39 VGPRs;
-    // 256-thread blocks with windows up to 13: the plane-reading variant stages the E words of L, which wins back a little more
-    // than the prep pass costs on large jobs -- 64 x 1080p at 9x9 / D = 64: 1.865 + 0.086 ms against 1.969)
+    // (64-thread blocks with windows from 13 columns up: two staging units per lane, the direct variant spills 8-39 VGPRs.
+    // Until late in round 3 large jobs of 256-thread blocks with windows up to 13 kept the planes too: that variant stages the E words of
+    // L, which won back a little more than the prep pass cost.  Since the in-place masks of the on-the-fly kernels the direct variant is
+    // as fast or faster on every such job -- 64 x 1080p at 9x9 / D = 64: 1.738 ms against 1.747 with the pass, 13x13: 1.90 against 2.01,
+    // tools/step_direct_ab.py -- without scratch planes and with half the traffic.)
     // Round 3: interleaved BGR frames -- what cv::imread hands the reference (SAD.cpp:65-66) -- are read in place too where the variant
     // that gathers channel 0 itself is built (17-32 disparities, windows up to 8: strip_otf_kernels.hip): the reference's own call,
     // one BGR pair at winSize 7 / DSR 30, is then one launch.
     bool direct = use_strip && use_otf && !host_inputs && env().direct != 0 && cols + 32 < 65000 &&
-                  (channels == 1 ? (!(otf_ng == 1 && win >= 13 && env().direct < 0) &&
-                                    !(otf_ng >= 4 && win <= 13 && (long)n_pairs * nvalid * cols > 4000000L && env().direct < 0))
+                  (channels == 1 ? !(otf_ng == 1 && win >= 13 && env().direct < 0)
                                  : pick_strip_otf_kernel(win, otf_ng, true, nullptr, channels) != nullptr) &&
                   (int64_t)need_rows * (pitchL > pitchR ? pitchL : pitchR) < 0x7ff00000LL;
     if (direct) {

@@ -103,6 +103,6 @@ def test_config1_batch_of_256_and_config2_batch_whole_frames():
     pairs = [oracle.rds(20 + i, 1920, 1080, 8 + i, 40 + i, 0) for i in range(8)]
     ctx = oa.Context(0)
     out = oa.compute_batch_device(dev(np.stack([p[0] for p in pairs])), dev(np.stack([p[1] for p in pairs])), 9, 64, ctx=ctx).cpu().numpy()
-    assert ctx.last_kernel() == "sad_strip_otf_kernel<9,4>"        # large 64-disparity jobs, windows up to 13: prep pass + staged E words of L
+    assert ctx.last_kernel() == "sad_strip_otf_kernel<9,4>+direct"  # read in place like every single-channel device job (late round 3)
     for i, (L, R) in enumerate(pairs):
         assert_same(out[i], oracle.box(L, R, 9, 64), "cfg2 pair %d" % i)

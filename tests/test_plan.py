@@ -12,7 +12,7 @@ def test_baseline_configurations_get_the_documented_kernels():
     p = oa.plan(288, 384, 1, 256, 7, 30)                    # config 1 as a batch of grey frames: read in place, two frames per group
     assert p["kernel"] == "sad_strip_otf_kernel<7,2>+direct" and p["scratch"] == 0 and p["FG"] == 2 and p["bx"] == 3
     p = oa.plan(1080, 1920, 1, 64, 9, 64)                   # config 2
-    assert p["kernel"] == "sad_strip_otf_kernel<9,4>" and p["FG"] == 2 and p["bx"] == 15 and p["tail"] > 0
+    assert p["kernel"] == "sad_strip_otf_kernel<9,4>+direct" and p["prep"] == 0 and p["FG"] == 2 and p["bx"] == 15 and p["tail"] > 0
     p = oa.plan(2160, 3840, 1, 32, 15, 128)                 # config 3
     assert p["kernel"] == "sad_strip_kernel<15>+direct" and p["threads"] == 512 and p["FG"] == 1 and p["bx"] == 15 and p["prep"] == 0 and p["scratch"] == 0
     p = oa.plan(4320, 7680, 1, 4, 21, 256)                  # config 4
@@ -29,7 +29,7 @@ def test_baseline_configurations_get_the_documented_kernels():
     assert oa.plan(100, 100, 1, 1, 50, 30, oa.FORCE_GENERIC)["matcher"] == "generic"
     assert oa.plan(7, 100, 1, 1, 7, 30)["matcher"] == "none"        # rows <= winSize: all-zero result, nothing to launch
     assert oa.plan(1080, 1920, 1, 1, 7, 30, oa.KERNEL_QUAD)["kernel"] == "sad_quad_lds_kernel<7,8>"
-    assert oa.plan(1080, 1920, 1, 32, 7, 100)["kernel"] == "sad_strip_otf_kernel<7,8>"     # D % 16 != 0 up to 128: poisoned sums
+    assert oa.plan(1080, 1920, 1, 32, 7, 100)["kernel"] == "sad_strip_otf_kernel<7,8>+direct"     # D % 16 != 0 up to 128: poisoned sums
     assert oa.plan(1080, 1920, 1, 32, 7, 112)["kernel"] == "sad_strip_kernel<7>+direct"
 
 

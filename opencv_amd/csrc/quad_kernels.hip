@@ -8,6 +8,9 @@
 //     so v_min_u32 on the register IS the first-minimum argmin (cost<<16 | k);
 //   * chunks of one quad live in different threads of the block and are merged through LDS once per row.
 // Arithmetic of getDisparity()/sub_kernel(), /root/reference/SAD.cpp:13-61.
+#ifndef SADBM_QUAD_PRIO_PHASE
+#define SADBM_QUAD_PRIO_PHASE 5                                // sad_quad_lds_kernel: issue priority by phase of the step (see its march loop; 0 none, 2: experiment builds)
+#endif
 #include "sadbm_internal.hpp"
 
 namespace sadbm_detail {
@@ -483,6 +486,9 @@ __global__ void __launch_bounds__(256, (KC == 16 ? (WIN <= 16 ? 4 : 3) : (WIN <=
         if (active) {
             // per-thread LDS pointers: one VGPR base per image, small immediate offsets per word
             march_pass_lds<WIN, KC, false>(lp0 + bo, rp0 + bo, RW, C);
+            // issue priority (s_setprio) as in the on-the-fly strip kernels: the SUB pass at the default, the ADD pass and the chunk minimum raised --
+            // -2.1 ... -3.9 % on windows 2, 3, 31, 40 (profiles/r03o_issue_priority.txt; passes raised and minimum at the default: -0.7 ... +2.4 %)
+            if (SADBM_QUAD_PRIO_PHASE == 5) __builtin_amdgcn_s_setprio(0);
             if (r >= WIN) march_pass_lds<WIN, KC, true>(lp0 + bo + ROWW, rp0 + bo + ROWW, RW, C);
         }
         if (more) {                                           // other buffer: last read in step r-1
@@ -498,11 +504,13 @@ __global__ void __launch_bounds__(256, (KC == 16 ? (WIN <= 16 ? 4 : 3) : (WIN <=
         const bool emit = r >= WIN - 1;                       // block-uniform
         uint32_t best[4] = {KEY_MAX, KEY_MAX, KEY_MAX, KEY_MAX};
         const int par = r & 1;
+        if (SADBM_QUAD_PRIO_PHASE == 5) __builtin_amdgcn_s_setprio(1); else if (SADBM_QUAD_PRIO_PHASE == 2) __builtin_amdgcn_s_setprio(0);
         if (emit) {
             if (active) chunk_min<WIN, KC>(C, k0, kmaxrel0, dlim, G::POISON ? false : slow, best);
             if (c > 0) merge[par * 256 + tid] = make_uint4(best[0], best[1], best[2], best[3]);
         }
         __syncthreads();
+        if (SADBM_QUAD_PRIO_PHASE == 2) __builtin_amdgcn_s_setprio(1);
         if (!emit) continue;
         const int y = yb + r - (WIN - 1);
         if (c == 0 && x0 < p.W) {
